@@ -1,0 +1,181 @@
+/*
+ * resnmtf_hip.h -- C-ABI of the MI355X-native ResNMTF multiplicative-update inner loop.
+ *
+ * The reference (eso28599/resnmtf, pure R) has NO native boundary (NAMESPACE:1-4 has no
+ * useDynLib, there is no src/).  The seam is cut around the body of the iteration loop of
+ * res_nmtf_inner (R/main.r:48-109): {update_matrices x T, calculate_error x T} plus the
+ * post-loop normalisation_check (R/utils.r:176-195) and the binary cluster matrices of
+ * obtain_biclusters (R/obtain_bicl.r:162-180).  Each entry point below cites the reference
+ * code it replaces.  See INTEGRATION.md for the R-side .Call() binding.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every call returns 0 on success, non-zero on error; resnmtf_last_error() gives the text.
+ *     No exception crosses the ABI.
+ *   - all host matrices are fp64 COLUMN-MAJOR (R's native layout): element (i, j) of an
+ *     r x c matrix is at [i + j * r].  Vectors are plain fp64 arrays.
+ *   - the caller owns every host buffer; the library copies during the call.  The handle owns
+ *     all device memory.  A handle is not re-entrant; calls block unless stated otherwise.
+ *   - views, rows and columns are 0-based.
+ *   - there is NO CPU fallback: every compute entry point fails with RESNMTF_ERR_NO_DEVICE when
+ *     no gfx950 device is usable.
+ */
+#ifndef RESNMTF_HIP_H
+#define RESNMTF_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RESNMTF_ABI_VERSION 1
+#define RESNMTF_MAX_K 64
+
+enum {
+  RESNMTF_OK = 0,
+  RESNMTF_ERR_INVALID = 1,   /* bad argument / call order */
+  RESNMTF_ERR_NO_DEVICE = 2, /* no usable HIP device */
+  RESNMTF_ERR_HIP = 3,       /* a HIP runtime call failed */
+  RESNMTF_ERR_ALLOC = 4,
+  RESNMTF_ERR_STATE = 5      /* handle not prepared / view not owned */
+};
+
+/* factor selectors for resnmtf_factor_device_ptr */
+enum { RESNMTF_FACTOR_F = 0, RESNMTF_FACTOR_G = 1, RESNMTF_FACTOR_S = 2 };
+
+/* phases of one view's update inside a sweep (R/update_steps.r:282-314) */
+enum {
+  RESNMTF_PHASE_F = 0, /* update_f   (R/update_steps.r:141-165), incl. star_prod_relevant */
+  RESNMTF_PHASE_G = 1, /* update_g   (R/update_steps.r:180-207) + the X.G' pass feeding S and the next F */
+  RESNMTF_PHASE_S = 2  /* update_s   (220-240), update_lm x2 (249-251, 312-313), calculate_error (R/utils.r:157-166) */
+};
+
+typedef struct resnmtf_handle resnmtf_handle;
+
+typedef struct resnmtf_options {
+  int struct_size;        /* = sizeof(resnmtf_options); set by resnmtf_default_options */
+  int device_id;          /* HIP device ordinal; one process per GPU (default 0) */
+  void* stream;           /* hipStream_t to enqueue on; NULL = library-owned stream */
+  int use_graph;          /* 1 (default): capture one sweep into a hipGraph and replay it */
+  int check_every;        /* convergence mode: sweeps enqueued per host-side check (default 8) */
+  int target_workgroups;  /* split sizing of the streaming passes; 0 = default */
+  int time_kernels;       /* 1: bracket every streaming-pass launch with HIP events (eager mode) */
+  int reserved[8];
+} resnmtf_options;
+
+typedef struct resnmtf_pass_timing {
+  double xg_ms_total;     /* summed duration of the X.G streaming-pass launches */
+  double xtf_ms_total;    /* summed duration of the Xt.F streaming-pass launches */
+  long long xg_launches;
+  long long xtf_launches;
+  double xg_bytes;        /* algorithmic bytes of ONE X.G launch   */
+  double xtf_bytes;       /* algorithmic bytes of ONE Xt.F launch */
+  double xg_flops;        /* algorithmic flops of ONE X.G launch  */
+  double xtf_flops;
+} resnmtf_pass_timing;
+
+int resnmtf_abi_version(void);
+/* number of visible HIP devices (0 when none; never fails) */
+int resnmtf_device_count(void);
+void resnmtf_default_options(resnmtf_options* opts);
+/* text of the last error on this handle (or of the last failed resnmtf_create when h == NULL) */
+const char* resnmtf_last_error(const resnmtf_handle* h);
+
+/*
+ * Create a handle for n_views views; view v is n_rows[v] x n_cols[v] with k[v] biclusters
+ * (2 <= k <= RESNMTF_MAX_K).  owned[v] != 0 marks the views whose data matrix lives on THIS
+ * process' GPU (owned == NULL: all).  Non-owned views only have factor mirrors (F, G, S) that
+ * the host refreshes through resnmtf_factor_device_ptr + its own exchange (RCCL broadcast).
+ * Replaces: the R lists built by res_nmtf_inner, R/main.r:38-48.
+ */
+int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int* k,
+                   const int* owned, const resnmtf_options* opts, resnmtf_handle** out);
+int resnmtf_destroy(resnmtf_handle* h);
+
+/*
+ * Upload the data matrix of an owned view: x is n x m fp64 column-major, ALREADY non-negative
+ * and column-L1-normalised (what check_inputs produces, R/utils.r:416,422).  Also computes
+ * data_norms[v] = ||X||_F^2 (R/main.r:48) on the device.
+ */
+int resnmtf_set_view(resnmtf_handle* h, int v, const double* x);
+
+/*
+ * Initial factors of view v (owned or mirror): F n x k, S k x k, G m x k, column-major.
+ * lambda / mu may be NULL: they are then colSums(F) / colSums(G), the reference's
+ * explicit-init branch (R/update_steps.r:49-56).
+ */
+int resnmtf_set_factors(resnmtf_handle* h, int v, const double* F, const double* S,
+                        const double* G, const double* lambda, const double* mu);
+
+/*
+ * Restriction matrices, n_views x n_views column-major, ALREADY symmetrised with zero diagonal
+ * (the output of init_rest_mats, R/update_steps.r:12-24).  NULL = all zero.
+ */
+int resnmtf_set_restrictions(resnmtf_handle* h, const double* phi, const double* xi,
+                             const double* psi);
+
+/*
+ * Shared rows (columns) between views v and w, as index pairs: row idx_v[t] of view v carries
+ * the same NAME as row idx_w[t] of view w.  This is the integer form of
+ * row_indices[[v]][[as.character(w)]] (R/utils.r:560-601) after match() against the row names.
+ * count = -1 encodes the reference's NA ("no shared names"): star_prod_relevant then skips
+ * the numerator term for w (R/utils.r:70) while update_f still adds phi[w,v]*F to the
+ * denominator (R/update_steps.r:158).  Pairs that were never set default to NA.
+ * Must be called for (v, w) and for (w, v) separately, as the reference keeps one map per
+ * ordered pair.
+ */
+int resnmtf_set_shared_rows(resnmtf_handle* h, int v, int w, int count, const int* idx_v,
+                            const int* idx_w);
+int resnmtf_set_shared_cols(resnmtf_handle* h, int v, int w, int count, const int* idx_v,
+                            const int* idx_w);
+
+/*
+ * Run the loop of res_nmtf_inner (R/main.r:50-109) on a handle that owns every view.
+ *   n_iters  > 0 : fixed number of sweeps (R/main.r:83-108).
+ *   n_iters == 0 : convergence mode, stop after the first sweep t with
+ *                  |mean_err_t - mean_err_{t-1}| <= tol, mean_err_0 = 0 (R/main.r:53-81;
+ *                  the reference uses tol = 1e-6), or after max_iters sweeps (a guard the
+ *                  reference lacks; max_iters <= 0 means err_capacity).
+ * all_err[t] receives mean over views of ||X - F S G^T||_F^2 / ||X||_F^2 after sweep t
+ * (All_Error, R/main.r:78,104); err_capacity is the length of all_err.  iters_done receives
+ * the number of sweeps executed.  May be called repeatedly; state carries over.
+ */
+int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, double* all_err,
+                int err_capacity, int* iters_done);
+
+/* Raw (un-normalised) state, so that a caller can resume exactly.  Any pointer may be NULL. */
+int resnmtf_get_factors(resnmtf_handle* h, int v, double* F, double* S, double* G,
+                        double* lambda, double* mu);
+
+/*
+ * normalisation_check (R/utils.r:176-195) followed by the binary cluster matrices of
+ * obtain_biclusters with remove_spurious = FALSE (R/obtain_bicl.r:162-180):
+ * row_clusters = 1[F > 1/n][, relations], col_clusters = 1[G > 1/m], relations[j] =
+ * which.max(S[, j]).  Does not modify the handle's state.  Any output pointer may be NULL.
+ */
+int resnmtf_finalise(resnmtf_handle* h, int v, double* F, double* S, double* G,
+                     double* row_clusters, double* col_clusters);
+
+/* ---- phase-level entry points (views sharded one-per-GPU; host does the exchange) ---- */
+
+/* Validate state, build the device coupling tables, run the first X.G pass of every owned
+ * view.  Called implicitly by resnmtf_run.  Asynchronous on the handle's stream. */
+int resnmtf_prepare(resnmtf_handle* h);
+/* Enqueue one phase of owned view v on the handle's stream (asynchronous).  sweep is the
+ * 0-based sweep index the error of RESNMTF_PHASE_S is filed under. */
+int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep);
+/* Device address and byte size of a factor of view v (fp64 row-major [len][k]; S is [k][k]).
+ * The host may overwrite a mirror (non-owned view) with an exchange enqueued on the handle's
+ * stream, or read an owned factor as the source of one. */
+int resnmtf_factor_device_ptr(resnmtf_handle* h, int v, int which, void** ptr, size_t* bytes);
+/* Per-view relative errors of sweeps [first, first + count) of an owned view (blocking). */
+int resnmtf_view_errors(resnmtf_handle* h, int v, int first, int count, double* out);
+int resnmtf_synchronize(resnmtf_handle* h);
+/* Accumulated streaming-pass timings (options.time_kernels = 1); reset when reset != 0. */
+int resnmtf_pass_timings(resnmtf_handle* h, resnmtf_pass_timing* out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RESNMTF_HIP_H */

@@ -1,0 +1,93 @@
+"""ctypes binding of libresnmtf_hip.so (the C-ABI declared in include/resnmtf_hip.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` /
+``python -m resnmtf_amd.build``.  There is deliberately no fallback: if the library is
+missing, or no gfx950 device is usable, every compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libresnmtf_hip.so")
+
+OK = 0
+ERR_NAMES = {1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "ALLOC", 5: "STATE"}
+FACTOR_F, FACTOR_G, FACTOR_S = 0, 1, 2
+PHASE_F, PHASE_G, PHASE_S = 0, 1, 2
+MAX_K = 64
+
+
+class ResnmtfError(RuntimeError):
+    def __init__(self, code: int, text: str):
+        super().__init__(f"resnmtf_hip error {code} ({ERR_NAMES.get(code, '?')}): {text}")
+        self.code = code
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int), ("device_id", C.c_int), ("stream", C.c_void_p),
+        ("use_graph", C.c_int), ("check_every", C.c_int), ("target_workgroups", C.c_int),
+        ("time_kernels", C.c_int), ("reserved", C.c_int * 8),
+    ]
+
+
+class PassTiming(C.Structure):
+    _fields_ = [
+        ("xg_ms_total", C.c_double), ("xtf_ms_total", C.c_double),
+        ("xg_launches", C.c_longlong), ("xtf_launches", C.c_longlong),
+        ("xg_bytes", C.c_double), ("xtf_bytes", C.c_double),
+        ("xg_flops", C.c_double), ("xtf_flops", C.c_double),
+    ]
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_h = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/resnmtf_hip.h declares
+SIGNATURES = {
+    "resnmtf_abi_version": (C.c_int, []),
+    "resnmtf_device_count": (C.c_int, []),
+    "resnmtf_default_options": (None, [C.POINTER(Options)]),
+    "resnmtf_last_error": (C.c_char_p, [_h]),
+    "resnmtf_create": (C.c_int, [C.c_int, _ip, _ip, _ip, _ip, C.POINTER(Options), C.POINTER(_h)]),
+    "resnmtf_destroy": (C.c_int, [_h]),
+    "resnmtf_set_view": (C.c_int, [_h, C.c_int, _dp]),
+    "resnmtf_set_factors": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "resnmtf_set_restrictions": (C.c_int, [_h, _dp, _dp, _dp]),
+    "resnmtf_set_shared_rows": (C.c_int, [_h, C.c_int, C.c_int, C.c_int, _ip, _ip]),
+    "resnmtf_set_shared_cols": (C.c_int, [_h, C.c_int, C.c_int, C.c_int, _ip, _ip]),
+    "resnmtf_run": (C.c_int, [_h, C.c_int, C.c_double, C.c_int, _dp, C.c_int, _ip]),
+    "resnmtf_get_factors": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "resnmtf_finalise": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "resnmtf_prepare": (C.c_int, [_h]),
+    "resnmtf_phase": (C.c_int, [_h, C.c_int, C.c_int, C.c_int]),
+    "resnmtf_factor_device_ptr": (C.c_int, [_h, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "resnmtf_view_errors": (C.c_int, [_h, C.c_int, C.c_int, C.c_int, _dp]),
+    "resnmtf_synchronize": (C.c_int, [_h]),
+    "resnmtf_pass_timings": (C.c_int, [_h, C.POINTER(PassTiming), C.c_int]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the in-tree HIP library; raises ImportError loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m resnmtf_amd.build` "
+            "(hipcc --offload-arch=gfx950).  resnmtf_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.resnmtf_abi_version() != 1:
+        raise ImportError("libresnmtf_hip.so ABI version mismatch")
+    _lib = lib
+    return lib

@@ -1,0 +1,179 @@
+"""Thin object wrapper over the C-ABI (include/resnmtf_hip.h): one ``Engine`` = one
+``resnmtf_handle`` = the device-resident state of the multiplicative-update loop on ONE GPU.
+
+Everything numeric happens in the HIP library; this module only marshals NumPy arrays
+(fp64, column-major, as R would hand them over) and raises on any error code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import ResnmtfError
+
+
+def _f64_colmajor(a, shape=None) -> np.ndarray:
+    arr = np.asfortranarray(np.asarray(a, dtype=np.float64))
+    if shape is not None and tuple(arr.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {tuple(arr.shape)}")
+    return arr
+
+
+def _dp(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def device_count() -> int:
+    return int(_lib.load().resnmtf_device_count())
+
+
+class Engine:
+    def __init__(self, n_rows: Sequence[int], n_cols: Sequence[int], k: Sequence[int],
+                 owned: Optional[Sequence[bool]] = None, device_id: int = 0, stream: int = 0,
+                 use_graph: bool = True, check_every: int = 8, target_workgroups: int = 0,
+                 time_kernels: bool = False):
+        self._lib = _lib.load()
+        self.n_views = len(n_rows)
+        self.n_rows = [int(x) for x in n_rows]
+        self.n_cols = [int(x) for x in n_cols]
+        self.k = [int(x) for x in k]
+        self.owned = [True] * self.n_views if owned is None else [bool(x) for x in owned]
+        opts = _lib.Options()
+        self._lib.resnmtf_default_options(C.byref(opts))
+        opts.device_id = int(device_id)
+        opts.stream = C.c_void_p(int(stream)) if stream else None
+        opts.use_graph = 1 if use_graph else 0
+        opts.check_every = int(check_every)
+        opts.target_workgroups = int(target_workgroups)
+        opts.time_kernels = 1 if time_kernels else 0
+        nr = np.asarray(self.n_rows, dtype=np.int32)
+        nc = np.asarray(self.n_cols, dtype=np.int32)
+        kk = np.asarray(self.k, dtype=np.int32)
+        ow = np.asarray([1 if o else 0 for o in self.owned], dtype=np.int32)
+        self._h = C.c_void_p()
+        rc = self._lib.resnmtf_create(self.n_views, _ip(nr), _ip(nc), _ip(kk), _ip(ow), C.byref(opts),
+                                      C.byref(self._h))
+        if rc != _lib.OK:
+            text = self._lib.resnmtf_last_error(None)
+            self._h = None
+            raise ResnmtfError(rc, text.decode() if text else "")
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc: int):
+        if rc != _lib.OK:
+            text = self._lib.resnmtf_last_error(self._h)
+            raise ResnmtfError(rc, text.decode() if text else "")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.resnmtf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------ inputs
+    def set_view(self, v: int, x):
+        x = _f64_colmajor(x, (self.n_rows[v], self.n_cols[v]))
+        self._check(self._lib.resnmtf_set_view(self._h, v, _dp(x)))
+
+    def set_factors(self, v: int, f, s, g, lam=None, mu=None):
+        k = self.k[v]
+        f = _f64_colmajor(f, (self.n_rows[v], k))
+        s = _f64_colmajor(s, (k, k))
+        g = _f64_colmajor(g, (self.n_cols[v], k))
+        lam = None if lam is None else np.ascontiguousarray(lam, dtype=np.float64)
+        mu = None if mu is None else np.ascontiguousarray(mu, dtype=np.float64)
+        self._check(self._lib.resnmtf_set_factors(self._h, v, _dp(f), _dp(s), _dp(g), _dp(lam), _dp(mu)))
+
+    def set_restrictions(self, phi=None, xi=None, psi=None):
+        mats = []
+        for m in (phi, xi, psi):
+            mats.append(None if m is None else _f64_colmajor(m, (self.n_views, self.n_views)))
+        self._check(self._lib.resnmtf_set_restrictions(self._h, _dp(mats[0]), _dp(mats[1]), _dp(mats[2])))
+
+    def _set_shared(self, fn, v, w, idx_v, idx_w):
+        if idx_v is None:           # NA
+            self._check(fn(self._h, v, w, -1, None, None))
+            return
+        iv = np.ascontiguousarray(idx_v, dtype=np.int32)
+        iw = np.ascontiguousarray(idx_w, dtype=np.int32)
+        if iv.shape != iw.shape:
+            raise ValueError("index arrays differ in length")
+        self._check(fn(self._h, v, w, int(iv.size), _ip(iv), _ip(iw)))
+
+    def set_shared_rows(self, v: int, w: int, idx_v, idx_w):
+        self._set_shared(self._lib.resnmtf_set_shared_rows, v, w, idx_v, idx_w)
+
+    def set_shared_cols(self, v: int, w: int, idx_v, idx_w):
+        self._set_shared(self._lib.resnmtf_set_shared_cols, v, w, idx_v, idx_w)
+
+    # ------------------------------------------------------------------ loop
+    def run(self, n_iters: Optional[int] = None, tol: float = 1.0e-6, max_iters: int = 100000):
+        """Fixed ``n_iters`` sweeps, or (``n_iters=None``) until |d mean err| <= tol.
+        Returns the All_Error vector of the sweeps executed."""
+        if n_iters is not None and n_iters <= 0:
+            raise ValueError("n_iters must be positive (None = run to convergence)")
+        cap = int(n_iters) if n_iters else int(max_iters)
+        errs = np.zeros(cap, dtype=np.float64)
+        done = C.c_int(0)
+        self._check(self._lib.resnmtf_run(self._h, int(n_iters or 0), float(tol), int(max_iters), _dp(errs), cap,
+                                          C.byref(done)))
+        return errs[:done.value].copy()
+
+    def prepare(self):
+        self._check(self._lib.resnmtf_prepare(self._h))
+
+    def phase(self, v: int, phase: int, sweep: int):
+        self._check(self._lib.resnmtf_phase(self._h, v, phase, sweep))
+
+    def synchronize(self):
+        self._check(self._lib.resnmtf_synchronize(self._h))
+
+    def factor_device_ptr(self, v: int, which: int):
+        ptr = C.c_void_p()
+        nbytes = C.c_size_t()
+        self._check(self._lib.resnmtf_factor_device_ptr(self._h, v, which, C.byref(ptr), C.byref(nbytes)))
+        return int(ptr.value), int(nbytes.value)
+
+    def view_errors(self, v: int, first: int, count: int) -> np.ndarray:
+        out = np.zeros(count, dtype=np.float64)
+        self._check(self._lib.resnmtf_view_errors(self._h, v, first, count, _dp(out)))
+        return out
+
+    # ------------------------------------------------------------------ outputs
+    def get_factors(self, v: int, with_lm: bool = True):
+        n, m, k = self.n_rows[v], self.n_cols[v], self.k[v]
+        f = np.zeros((n, k), order="F"); s = np.zeros((k, k), order="F"); g = np.zeros((m, k), order="F")
+        lam = np.zeros(k) if with_lm else None
+        mu = np.zeros(k) if with_lm else None
+        self._check(self._lib.resnmtf_get_factors(self._h, v, _dp(f), _dp(s), _dp(g), _dp(lam), _dp(mu)))
+        return f, s, g, lam, mu
+
+    def finalise(self, v: int):
+        n, m, k = self.n_rows[v], self.n_cols[v], self.k[v]
+        f = np.zeros((n, k), order="F"); s = np.zeros((k, k), order="F"); g = np.zeros((m, k), order="F")
+        rc = np.zeros((n, k), order="F"); cc = np.zeros((m, k), order="F")
+        self._check(self._lib.resnmtf_finalise(self._h, v, _dp(f), _dp(s), _dp(g), _dp(rc), _dp(cc)))
+        return f, s, g, rc, cc
+
+    def pass_timings(self, reset: bool = False) -> dict:
+        t = _lib.PassTiming()
+        self._check(self._lib.resnmtf_pass_timings(self._h, C.byref(t), 1 if reset else 0))
+        return {name: getattr(t, name) for name, _ in _lib.PassTiming._fields_}

