@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- multiplicative-update iterations/sec of the ResNMTF inner loop on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one full sweep of update_matrices + calculate_error (R/main.r:84-108) over all
+views.  N = 1: BASELINE.json configs[1] (c2: one view 10000 x 2000, k = 16, synthetic planted
+blocks).  N > 1 (launched by torch.distributed.run, one rank per GPU): N
+phi-coupled c2-shaped views, one per GPU, F blocks exchanged through torch.distributed (RCCL)
+in the reference's Gauss-Seidel order -- weak scaling, per-GPU work fixed.
+
+``value`` = view-updates per second = steps x n_views / wall (inputs resident in HBM before the
+timed region).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+METRIC = "multiplicative-update iters/sec (all views)"
+
+
+def cpu_baseline(prob, warm: int = 2, timed: int = 10) -> dict:
+    """The oracle (literal fp64 restatement: four passes over X per sweep, materialised
+    residual -- the BLAS call sequence R would issue) on the host cores; NumPy/OpenBLAS."""
+    from oracle import resnmtf_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    data = prob.data
+    cur_f, cur_s, cur_g = list(prob.init_f), list(prob.init_s), list(prob.init_g)
+    lam, mu = O.explicit_init_lm(cur_f, cur_g)
+    rn, cn = prob.row_names, prob.col_names
+    ri, ci = O.reorder_data(rn), O.reorder_data(cn)
+    norms = np.array([np.linalg.norm(d, "fro") ** 2 for d in data])
+
+    def sweep():
+        nonlocal cur_f, cur_s, cur_g, lam, mu
+        cur_f, cur_s, cur_g, lam, mu = O.update_matrices(data, cur_f, cur_s, cur_g, lam, mu, prob.phi, prob.xi,
+                                                         prob.psi, ri, ci, rn, cn)
+        return O.calculate_error(data, cur_f, cur_s, cur_g, norms)
+    for _ in range(warm):
+        sweep()
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        sweep()
+    dt = time.perf_counter() - t0
+    return {"value": timed * len(data) / dt, "unit": "view-updates/s", "cores": int(threads), "kind": "port",
+            "sample": f"{timed} sweeps (after {warm} warm-up) of the same workload, NumPy+OpenBLAS fp64, "
+                      f"{threads} threads; R unavailable on the box"}
+
+
+def run_single(args) -> dict:
+    import torch
+    from resnmtf_amd import synth
+    from resnmtf_amd.engine import Engine
+
+    prob = synth.config("c2")
+    n, m = prob.data[0].shape
+    k = prob.k
+
+    def make_engine(**kw):
+        e = Engine([n], [m], [k], device_id=0, **kw)
+        t0 = time.perf_counter()
+        e.set_view(0, prob.data[0])
+        up = time.perf_counter() - t0
+        e.set_restrictions(None, None, None)
+        e.set_factors(0, prob.init_f[0], prob.init_s[0], prob.init_g[0])
+        return e, up
+
+    eng, upload_s = make_engine()
+    if args.warmup > 0:
+        eng.run(args.warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    errs = eng.run(args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert len(errs) == args.steps and np.isfinite(errs).all()
+    eng.close()
+
+    # roofline leg: the same K sweeps, eager, every streaming-pass launch bracketed by HIP events
+    # on the library's stream (the dominant kernel is atb_pass_kernel: X.G and Xt.F passes)
+    eng2, _ = make_engine(time_kernels=True)
+    if args.warmup > 0:
+        eng2.run(min(args.warmup, 20))
+    eng2.pass_timings(reset=True)
+    eng2.run(args.steps)
+    t = eng2.pass_timings()
+    eng2.close()
+    launches = t["xg_launches"] + t["xtf_launches"]
+    pass_ms = (t["xg_ms_total"] + t["xtf_ms_total"]) / max(launches, 1)
+    bytes_per_launch = (t["xg_bytes"] * t["xg_launches"] + t["xtf_bytes"] * t["xtf_launches"]) / max(launches, 1)
+    achieved = bytes_per_launch / (pass_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "atb_pass_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_us": round(pass_ms * 1e3, 3), "launches": int(launches),
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "xg_avg_us": round(t["xg_ms_total"] / max(t["xg_launches"], 1) * 1e3, 3),
+                "xtf_avg_us": round(t["xtf_ms_total"] / max(t["xtf_launches"], 1) * 1e3, 3),
+                "mfma_tflops": round((t["xg_flops"] + t["xtf_flops"]) / 2 / (pass_ms * 1e-3) / 1e12, 2)}
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(traffic_file):          # HBM bytes per launch from the PMC passes (profiles/README.md)
+        try:
+            roofline["traffic"] = json.load(open(traffic_file)).get("atb_pass_kernel_bytes_per_launch")
+        except Exception:
+            pass
+
+    cpu = cpu_baseline(prob) if not args.no_cpu_baseline else None
+    value = args.steps * 1 / dt
+    return {
+        "metric": METRIC, "value": round(value, 2), "unit": "view-updates/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "c2: 1 view 10000x2000, k=16, fixed sweeps (BASELINE.json configs[1])",
+                   "n_views": 1, "rows": n, "cols": m, "k": k, "final_error": float(errs[-1]),
+                   "arithmetic": "fp32 X + f32 MFMA accumulate for X.G / Xt.F; fp64 factors and epilogues",
+                   "upload_s_pcie_inclusive": round(upload_s, 4)},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+
+
+def run_sharded(args) -> dict:
+    import torch
+    import torch.distributed as dist
+    from resnmtf_amd import sharded, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    n_views = world
+    n, m, k = 10000, 2000, 16
+    # every rank builds only the view it owns (same seeds as synth.make_problem) + all initial factors
+    prob = sharded.local_problem(n_views, (n, m), k, phi=200.0, owned=[rank])
+    drv = sharded.ShardedSweep(prob, owner_of=list(range(n_views)), rank=rank, world=world,
+                               device_index=local_rank)
+    drv.run(args.warmup)
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    drv.run(args.steps)
+    dist.barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    errs = drv.mean_errors()
+    drv.close()
+    dist.destroy_process_group()
+    if rank != 0:
+        return {}
+    return {
+        "metric": METRIC, "value": round(args.steps * n_views / dt, 2), "unit": "view-updates/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{n_views} phi-coupled views 10000x2000 (all rows shared, phi=200), k=16, one view "
+                               "per GPU, F exchanged by ordered RCCL broadcasts (Gauss-Seidel order)",
+                   "n_views": n_views, "rows": n, "cols": m, "k": k,
+                   "final_error": float(errs[-1]) if len(errs) else None},
+        "roofline": None, "cpu_baseline": None,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    out = run_single(args) if args.gpus == 1 else run_sharded(args)
+    if out:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
