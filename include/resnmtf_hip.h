@@ -46,9 +46,11 @@ enum { RESNMTF_FACTOR_F = 0, RESNMTF_FACTOR_G = 1, RESNMTF_FACTOR_S = 2 };
 
 /* phases of one view's update inside a sweep (R/update_steps.r:282-314) */
 enum {
-  RESNMTF_PHASE_F = 0, /* update_f   (R/update_steps.r:141-165), incl. star_prod_relevant */
-  RESNMTF_PHASE_G = 1, /* update_g   (R/update_steps.r:180-207) + the X.G' pass feeding S and the next F */
-  RESNMTF_PHASE_S = 2  /* update_s   (220-240), update_lm x2 (249-251, 312-313), calculate_error (R/utils.r:157-166) */
+  RESNMTF_PHASE_F = 0, /* update_f (R/update_steps.r:141-165) incl. star_prod_relevant (R/utils.r:63-78) */
+  RESNMTF_PHASE_G = 1, /* Xt.F pass, update_g (R/update_steps.r:180-207), X.G' pass; update_s (220-240),
+                          update_lm x2 (249-251, 312-313) and calculate_error (R/utils.r:157-166) ride in
+                          the X.G' launch */
+  RESNMTF_PHASE_S = 2  /* no work: marks the point after which the view's new S may be exchanged */
 };
 
 typedef struct resnmtf_handle resnmtf_handle;
@@ -59,9 +61,16 @@ typedef struct resnmtf_options {
   void* stream;           /* hipStream_t to enqueue on; NULL = library-owned stream */
   int use_graph;          /* 1 (default): capture one sweep into a hipGraph and replay it */
   int check_every;        /* convergence mode: sweeps enqueued per host-side check (default 8) */
-  int target_workgroups;  /* split sizing of the streaming passes; 0 = default */
+  int target_workgroups;  /* waves per streaming pass (sizes splits x waves-per-workgroup); 0 = default 4096 */
   int time_kernels;       /* 1: bracket every streaming-pass launch with HIP events (eager mode) */
-  int reserved[8];
+  /* tuning overrides of the streaming-pass geometry (0 = automatic), see DESIGN.md section 5 */
+  int pass_waves;         /* waves per workgroup: 1, 2, 4, 8 or 16 */
+  int pass_splits_xg;     /* row splits of the X.G pass */
+  int pass_splits_xtf;    /* row splits of the Xt.F pass */
+  int pass_lds_pad_kb;    /* extra dynamic LDS per workgroup (caps workgroups per CU) */
+  int update_blocks;      /* workgroups per factor-update launch (default 256) */
+  int no_pitch_pad;       /* 1: do not pad row pitches that are multiples of 4 KiB (A/B testing) */
+  int reserved[2];
 } resnmtf_options;
 
 typedef struct resnmtf_pass_timing {
@@ -159,15 +168,20 @@ int resnmtf_finalise(resnmtf_handle* h, int v, double* F, double* S, double* G,
 
 /* ---- phase-level entry points (views sharded one-per-GPU; host does the exchange) ---- */
 
-/* Validate state, build the device coupling tables, run the first X.G pass of every owned
- * view.  Called implicitly by resnmtf_run.  Asynchronous on the handle's stream. */
+/* Size the per-sweep error buffer for `sweeps` sweeps (phase mode; resnmtf_run sizes it itself).
+ * Must precede resnmtf_prepare. */
+int resnmtf_reserve_sweeps(resnmtf_handle* h, int sweeps);
+/* Validate state, build the device coupling tables, reset the sweep counter and run the first
+ * X.G pass of every owned view.  Called implicitly by resnmtf_run.  Asynchronous on the stream. */
 int resnmtf_prepare(resnmtf_handle* h);
-/* Enqueue one phase of owned view v on the handle's stream (asynchronous).  sweep is the
- * 0-based sweep index the error of RESNMTF_PHASE_S is filed under. */
+/* Enqueue one phase of owned view v (asynchronous).  `sweep` is the 0-based index of the sweep being
+ * executed since resnmtf_prepare.  Within a sweep the caller visits the owned views in index order:
+ * PHASE_F, [exchange F], PHASE_G, [exchange G], PHASE_S, [exchange S].  Exchanges enqueued on the
+ * handle's stream are ordered against every kernel that reads or writes the exchanged factor. */
 int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep);
 /* Device address and byte size of a factor of view v (fp64 row-major [len][k]; S is [k][k]).
  * The host may overwrite a mirror (non-owned view) with an exchange enqueued on the handle's
- * stream, or read an owned factor as the source of one. */
+ * stream, or read an owned factor as the source of one (S: after PHASE_S). */
 int resnmtf_factor_device_ptr(resnmtf_handle* h, int v, int which, void** ptr, size_t* bytes);
 /* Per-view relative errors of sweeps [first, first + count) of an owned view (blocking). */
 int resnmtf_view_errors(resnmtf_handle* h, int v, int first, int count, double* out);

@@ -29,7 +29,9 @@ class Options(C.Structure):
     _fields_ = [
         ("struct_size", C.c_int), ("device_id", C.c_int), ("stream", C.c_void_p),
         ("use_graph", C.c_int), ("check_every", C.c_int), ("target_workgroups", C.c_int),
-        ("time_kernels", C.c_int), ("reserved", C.c_int * 8),
+        ("time_kernels", C.c_int), ("pass_waves", C.c_int), ("pass_splits_xg", C.c_int),
+        ("pass_splits_xtf", C.c_int), ("pass_lds_pad_kb", C.c_int), ("update_blocks", C.c_int),
+        ("no_pitch_pad", C.c_int), ("reserved", C.c_int * 2),
     ]
 
 
@@ -62,6 +64,7 @@ SIGNATURES = {
     "resnmtf_run": (C.c_int, [_h, C.c_int, C.c_double, C.c_int, _dp, C.c_int, _ip]),
     "resnmtf_get_factors": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "resnmtf_finalise": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "resnmtf_reserve_sweeps": (C.c_int, [_h, C.c_int]),
     "resnmtf_prepare": (C.c_int, [_h]),
     "resnmtf_phase": (C.c_int, [_h, C.c_int, C.c_int, C.c_int]),
     "resnmtf_factor_device_ptr": (C.c_int, [_h, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),

@@ -1,14 +1,16 @@
 // resnmtf_hip.hip -- host side of libresnmtf_hip.so: handle, device memory, launch schedule,
 // hipGraph capture and the C-ABI declared in include/resnmtf_hip.h.
 //
-// Schedule of one sweep (R/update_steps.r:272-319) for owned views v = 0..V-1, in order:
-//     F_v :  factor_update<F>(U_v)                       U_v = X_v G_v from the previous pass
-//     G_v :  pass Xt.F  ->  factor_update<G>(T_v)  ->  pass X.G'   (also G'^T G' and T^T G')
-//   then, for v = 0..V-1:
-//     S_v :  s_update (S, lambda, mu, error, next F coefficients)
-// S_v may trail the other views' F/G updates because no F or G rule reads another view's S and
-// the xi coupling only needs S_w (w < v) updated first -- the order inside the trailing loop.
-// A run starts with one X.G pass per view (state after set_factors has no U yet).
+// Schedule of one sweep (R/update_steps.r:272-319) for owned views v = 0..V-1, in order, ONE stream:
+//   F_v          factor_update<F>   update_f, reads U_v = X_v G_v; emits partial F'^T F', colSums(F')
+//   pass Xt.F    T_v = X_v^T F_v'   + workgroup 0: kk_f (F'^T F', G coefficients)
+//   G_v          factor_update<G>   update_g, reads T_v; emits partial G'^T G', T^T G', colSums(G')
+//   pass X.G'    U_v = X_v G_v'     + workgroup 0: kk_s (update_s, update_lm, error, next F coefficients)
+// Every k x k chain depends only on the factor that was just updated, so it runs as ONE extra
+// workgroup of the streaming-pass launch that follows that update and is hidden behind it.
+// Cross-view coupling (phi/psi: running F/G; xi: running S) is ordered by the stream.
+// A run starts with a prologue per view: Gram of the current G, then an X.G pass whose
+// workgroup 0 runs kk_s in mode 0 (F coefficients only).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -38,19 +40,22 @@ struct ViewState {
   int n = 0, m = 0, k = 0, KP = 16, NT = 1;
   bool owned = true, has_x = false, has_factors = false;
   int n_pad = 0, m_pad = 0;
+  int ldx = 0, ldxt = 0;         // leading dimensions of X32 / Xt32 (floats), kept off large powers of two
   float *X32 = nullptr, *Xt32 = nullptr;
   double* xnorm2 = nullptr;
   double *F = nullptr, *G = nullptr, *S = nullptr, *lambda = nullptr, *mu = nullptr;
-  float *F32 = nullptr, *G32 = nullptr, *T32 = nullptr;
-  int nsplit_xg = 1, rps_xg = 16, cols_total_xg = 0;
-  int nsplit_xtf = 1, rps_xtf = 16, cols_total_xtf = 0;
+  float *F32 = nullptr, *G32 = nullptr;
+  int nsplit_xg = 1, rps_xg = 64, nw_xg = 4;
+  int nsplit_xtf = 1, rps_xtf = 64, nw_xtf = 4;
   float *Pxg = nullptr, *Pxtf = nullptr;
   int rpbF = 16, nblkF = 1, rpbG = 16, nblkG = 1;
-  double *colsumF_part = nullptr, *colsumG_part = nullptr;
-  double *FtF = nullptr, *Ma_F = nullptr, *Md_F = nullptr;
+  double *partF = nullptr, *partG = nullptr;
+  double *FtF = nullptr, *FtFS = nullptr, *cF = nullptr;
+  double *Ma_F = nullptr, *Md_F = nullptr, *Ma_G = nullptr, *Md_G = nullptr;
   std::vector<SharedMap> row_map, col_map;   // indexed by the other view
-  UpdateArgs argF{}, argG{};
-  SArgs argS{};
+  UpdateArgs argF{}, argG{}, argGram{};
+  KKFArgs argKF{};
+  KKSArgs argKS{};
   PassArgs passXG{}, passXtF{};
 };
 
@@ -60,13 +65,13 @@ struct resnmtf_handle {
   int V = 0;
   std::vector<ViewState> views;
   resnmtf_options opt{};
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;       // every kernel of the loop (+ the host's exchanges)
   bool own_stream = false;
   std::vector<double> phi, xi, psi;   // V x V column-major
   SweepCtl* ctl = nullptr;
   double* err = nullptr;              // [err_cap][V]
-  double* mean_err = nullptr;         // [err_cap]
-  int err_cap = 4096;
+  int err_cap = 0;
+  int last_owned = -1;
   bool prepared = false;
   bool all_owned = true;
   // graphs
@@ -106,8 +111,8 @@ hipError_t dev_alloc_zero(T** p, size_t count) {
 }
 
 void free_view(ViewState& v) {
-  void* ptrs[] = {v.X32, v.Xt32, v.xnorm2, v.F, v.G, v.S, v.lambda, v.mu, v.F32, v.G32, v.T32, v.Pxg, v.Pxtf,
-                  v.colsumF_part, v.colsumG_part, v.FtF, v.Ma_F, v.Md_F};
+  void* ptrs[] = {v.X32, v.Xt32, v.xnorm2, v.F, v.G, v.S, v.lambda, v.mu, v.F32, v.G32, v.Pxg, v.Pxtf,
+                  v.partF, v.partG, v.FtF, v.FtFS, v.cF, v.Ma_F, v.Md_F, v.Ma_G, v.Md_G};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& mp : v.row_map)
@@ -133,38 +138,97 @@ void to_col_major(const std::vector<double>& src, int rows, int cols, double* ds
     for (int i = 0; i < rows; ++i) dst[(size_t)j * rows + i] = src[(size_t)i * cols + j];
 }
 
-size_t update_smem_bytes(int KP, bool is_g) {
-  const int RG = 256 / KP;
-  return sizeof(double) * ((size_t)(is_g ? 4 : 2) * KP * KP + 3 * (size_t)RG * KP);
+size_t update_smem_bytes(int KP) {
+  const int RG = UPDATE_THREADS / KP;
+  return sizeof(double) * ((size_t)2 * KP * KP + 3 * (size_t)RG * KP + 2 * UPDATE_THREADS);
 }
-size_t s_smem_bytes(int KP) { return sizeof(double) * ((size_t)4 * KP * KP + 256); }
+size_t kk_smem_bytes(int KP, int NW) { return sizeof(double) * ((size_t)4 * KP * KP + 2 * 64 * (size_t)NW); }
+size_t pass_smem_bytes(int KP, int NW) {
+  return std::max(sizeof(float) * (size_t)std::max(NW / 2, 1) * 64 * KP, kk_smem_bytes(KP, NW));
+}
+constexpr int kMaxLds = 160 * 1024;
+
+template <int NT, int NW, int UNROLL>
+hipError_t set_pass_attr() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kkf_kernel<NT, NW, UNROLL>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kks_kernel<NT, NW, UNROLL>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+}
 
 template <int KP>
 hipError_t set_smem_attrs() {
   hipError_t e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_update_kernel<KP, false>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)update_smem_bytes(KP, false));
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_update_kernel<KP, true>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)update_smem_bytes(KP, true));
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&s_update_kernel<KP>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)s_smem_bytes(KP));
+#define SET_ATTR(fn, bytes)                                                                                    \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fn), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               (int)(bytes))) != hipSuccess)                                                   \
+  return e
+  SET_ATTR((factor_update_kernel<KP, false, false, false>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, false, false, true>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, true, false, false>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, true, false, true>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, true, true, false>), update_smem_bytes(KP));
+#undef SET_ATTR
+  return hipSuccess;
 }
 
-void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg) {
-  const PassArgs& a = xg ? v.passXG : v.passXtF;
-  const int ntiles = a.cols_total / 64;
+hipError_t set_all_attrs() {
+  hipError_t e;
+#define TRY_ATTR(x) if ((e = (x)) != hipSuccess) return e
+  TRY_ATTR(set_smem_attrs<16>()); TRY_ATTR(set_smem_attrs<32>());
+  TRY_ATTR(set_smem_attrs<48>()); TRY_ATTR(set_smem_attrs<64>());
+  TRY_ATTR((set_pass_attr<1, 1, 8>())); TRY_ATTR((set_pass_attr<1, 2, 8>()));
+  TRY_ATTR((set_pass_attr<1, 4, 8>())); TRY_ATTR((set_pass_attr<1, 8, 8>())); TRY_ATTR((set_pass_attr<1, 16, 8>()));
+  TRY_ATTR((set_pass_attr<2, 1, 4>())); TRY_ATTR((set_pass_attr<2, 2, 4>()));
+  TRY_ATTR((set_pass_attr<2, 4, 4>())); TRY_ATTR((set_pass_attr<2, 8, 4>())); TRY_ATTR((set_pass_attr<2, 16, 4>()));
+  TRY_ATTR((set_pass_attr<3, 1, 4>())); TRY_ATTR((set_pass_attr<3, 2, 4>()));
+  TRY_ATTR((set_pass_attr<3, 4, 4>())); TRY_ATTR((set_pass_attr<3, 8, 4>()));
+  TRY_ATTR((set_pass_attr<4, 1, 4>())); TRY_ATTR((set_pass_attr<4, 2, 4>()));
+  TRY_ATTR((set_pass_attr<4, 4, 4>())); TRY_ATTR((set_pass_attr<4, 8, 4>()));
+#undef TRY_ATTR
+  return hipSuccess;
+}
+
+int max_pass_waves(int NT) { return NT <= 2 ? 16 : 8; }
+
+// xg = false: Xt.F pass + kk_f;  xg = true: X.G pass + kk_s (mode 0 = run prologue, 1 = full S update)
+void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, double tol, bool check_done) {
+  PassArgs a = xg ? v.passXG : v.passXtF;
+  a.check_done = check_done ? 1 : 0;
+  KKFArgs kf = v.argKF;
+  KKSArgs ks = v.argKS;
+  ks.mode = mode; ks.tol = tol;
   const int nsplit = xg ? v.nsplit_xg : v.nsplit_xtf;
-  dim3 grid(ntiles, nsplit), block(256);
+  const int nw = xg ? v.nw_xg : v.nw_xtf;
+  const dim3 grid(1 + a.ntiles * nsplit), block(64 * nw);
+  const size_t smem = std::min<size_t>(pass_smem_bytes(v.KP, nw) + (size_t)h->opt.pass_lds_pad_kb * 1024, kMaxLds);
   const bool timed = h->opt.time_kernels && h->ev_used + 2 <= h->ev.size();
   if (timed) (void)hipEventRecord(h->ev[h->ev_used], h->stream);
-  switch (v.NT) {
-    case 1: hipLaunchKernelGGL((atb_pass_kernel<1, 8>), grid, block, 0, h->stream, a); break;
-    case 2: hipLaunchKernelGGL((atb_pass_kernel<2, 4>), grid, block, 0, h->stream, a); break;
-    case 3: hipLaunchKernelGGL((atb_pass_kernel<3, 4>), grid, block, 0, h->stream, a); break;
-    default: hipLaunchKernelGGL((atb_pass_kernel<4, 4>), grid, block, 0, h->stream, a); break;
+#define LAUNCH_PASS(NTV, NWV, UV)                                                                          \
+  if (xg) hipLaunchKernelGGL((pass_kks_kernel<NTV, NWV, UV>), grid, block, smem, h->stream, a, ks);         \
+  else hipLaunchKernelGGL((pass_kkf_kernel<NTV, NWV, UV>), grid, block, smem, h->stream, a, kf)
+  switch (v.NT * 100 + nw) {
+    case 101: LAUNCH_PASS(1, 1, 8); break;
+    case 102: LAUNCH_PASS(1, 2, 8); break;
+    case 104: LAUNCH_PASS(1, 4, 8); break;
+    case 108: LAUNCH_PASS(1, 8, 8); break;
+    case 116: LAUNCH_PASS(1, 16, 8); break;
+    case 201: LAUNCH_PASS(2, 1, 4); break;
+    case 202: LAUNCH_PASS(2, 2, 4); break;
+    case 204: LAUNCH_PASS(2, 4, 4); break;
+    case 208: LAUNCH_PASS(2, 8, 4); break;
+    case 216: LAUNCH_PASS(2, 16, 4); break;
+    case 301: LAUNCH_PASS(3, 1, 4); break;
+    case 302: LAUNCH_PASS(3, 2, 4); break;
+    case 304: LAUNCH_PASS(3, 4, 4); break;
+    case 308: LAUNCH_PASS(3, 8, 4); break;
+    case 401: LAUNCH_PASS(4, 1, 4); break;
+    case 402: LAUNCH_PASS(4, 2, 4); break;
+    case 404: LAUNCH_PASS(4, 4, 4); break;
+    default: LAUNCH_PASS(4, 8, 4); break;
   }
+#undef LAUNCH_PASS
   if (timed) {
     (void)hipEventRecord(h->ev[h->ev_used + 1], h->stream);
     h->ev_kind[h->ev_used / 2] = xg ? 0 : 1;
@@ -172,13 +236,20 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg) {
   }
 }
 
-void launch_update(resnmtf_handle* h, const ViewState& v, bool is_g) {
-  const UpdateArgs& a = is_g ? v.argG : v.argF;
-  const int nblk = is_g ? v.nblkG : v.nblkF;
-  const size_t smem = update_smem_bytes(v.KP, is_g);
-#define LAUNCH_UPD(KPV)                                                                                        \
-  if (is_g) hipLaunchKernelGGL((factor_update_kernel<KPV, true>), dim3(nblk), dim3(256), smem, h->stream, a);   \
-  else hipLaunchKernelGGL((factor_update_kernel<KPV, false>), dim3(nblk), dim3(256), smem, h->stream, a)
+// kind: 0 = F update, 1 = G update, 2 = Gram of the current G only (run prologue)
+void launch_update(resnmtf_handle* h, const ViewState& v, int kind, bool check_done) {
+  UpdateArgs a = kind == 0 ? v.argF : (kind == 1 ? v.argG : v.argGram);
+  a.check_done = check_done ? 1 : 0;
+  const int nblk = kind == 0 ? v.nblkF : v.nblkG;
+  const size_t smem = update_smem_bytes(v.KP);
+#define LAUNCH_UPD_K(KPV, G_, GO_, C_) \
+  hipLaunchKernelGGL((factor_update_kernel<KPV, G_, GO_, C_>), dim3(nblk), dim3(UPDATE_THREADS), smem, h->stream, a)
+#define LAUNCH_UPD(KPV)                                                              \
+  if (kind == 2) LAUNCH_UPD_K(KPV, true, true, false);                               \
+  else if (kind == 0 && a.restricted) LAUNCH_UPD_K(KPV, false, false, true);         \
+  else if (kind == 0) LAUNCH_UPD_K(KPV, false, false, false);                        \
+  else if (a.restricted) LAUNCH_UPD_K(KPV, true, false, true);                       \
+  else LAUNCH_UPD_K(KPV, true, false, false)
   switch (v.NT) {
     case 1: LAUNCH_UPD(16); break;
     case 2: LAUNCH_UPD(32); break;
@@ -186,41 +257,29 @@ void launch_update(resnmtf_handle* h, const ViewState& v, bool is_g) {
     default: LAUNCH_UPD(64); break;
   }
 #undef LAUNCH_UPD
+#undef LAUNCH_UPD_K
 }
 
-void launch_s(resnmtf_handle* h, const ViewState& v, int mode, int sweep_offset, bool use_ctl_sweep) {
-  SArgs a = v.argS;
-  a.mode = mode;
-  a.sweep_offset = sweep_offset;
-  a.use_ctl_sweep = use_ctl_sweep ? 1 : 0;
-  const size_t smem = s_smem_bytes(v.KP);
-  switch (v.NT) {
-    case 1: hipLaunchKernelGGL((s_update_kernel<16>), dim3(1), dim3(256), smem, h->stream, a); break;
-    case 2: hipLaunchKernelGGL((s_update_kernel<32>), dim3(1), dim3(256), smem, h->stream, a); break;
-    case 3: hipLaunchKernelGGL((s_update_kernel<48>), dim3(1), dim3(256), smem, h->stream, a); break;
-    default: hipLaunchKernelGGL((s_update_kernel<64>), dim3(1), dim3(256), smem, h->stream, a); break;
-  }
+// ---- the phases of one view (see the header comment)
+void enqueue_phase_f(resnmtf_handle* h, const ViewState& v, bool checked) { launch_update(h, v, 0, checked); }
+void enqueue_phase_g(resnmtf_handle* h, const ViewState& v, double tol, bool checked) {
+  launch_pass(h, v, false, 1, tol, checked);
+  launch_update(h, v, 1, checked);
+  launch_pass(h, v, true, 1, tol, checked);
 }
-
-// the three phases of one view (see header comment)
-void enqueue_phase_f(resnmtf_handle* h, const ViewState& v) { launch_update(h, v, false); }
-void enqueue_phase_g(resnmtf_handle* h, const ViewState& v) {
-  launch_pass(h, v, false);
-  launch_update(h, v, true);
-  launch_pass(h, v, true);
-}
-void enqueue_phase_s(resnmtf_handle* h, const ViewState& v, int sweep_offset, bool use_ctl) {
-  launch_s(h, v, 1, sweep_offset, use_ctl);
+// run prologue of one view: Gram of the current G, then X.G pass + F coefficients (kk_s mode 0)
+void enqueue_prologue(resnmtf_handle* h, const ViewState& v) {
+  launch_update(h, v, 2, false);
+  launch_pass(h, v, true, 0, -1.0, false);
 }
 
 void enqueue_sweep(resnmtf_handle* h, double tol) {
+  const bool checked = tol >= 0.0;
   for (const auto& v : h->views) {
-    enqueue_phase_f(h, v);
-    enqueue_phase_g(h, v);
+    if (!v.owned) continue;
+    enqueue_phase_f(h, v, checked);
+    enqueue_phase_g(h, v, tol, checked);
   }
-  for (const auto& v : h->views) enqueue_phase_s(h, v, 0, true);
-  hipLaunchKernelGGL(end_sweep_kernel, dim3(1), dim3(64), 0, h->stream, h->ctl, h->err, h->V, h->err_cap,
-                     h->mean_err, tol);
 }
 
 void destroy_graphs(resnmtf_handle* h) {
@@ -255,14 +314,40 @@ int flush_timing(resnmtf_handle* h) {
   return RESNMTF_OK;
 }
 
-// sizes the splits of a streaming pass: ~target workgroups in total, row ranges multiples of 16
-void size_pass(int ntiles, int rows_pad, int target, int* nsplit, int* rps) {
-  int ns = std::max(1, (target + ntiles / 2) / ntiles);
-  ns = std::min(ns, rows_pad / 64);
-  ns = std::max(ns, 1);
-  int r = round_up(ceil_div(rows_pad, ns), 16);
+// sizes a streaming pass.  Measured on MI355X (tools/sweep_pass.py, tools/micro/pass_variants.hip):
+// 8 waves per workgroup, 16-24 steps of 4 rows per wave (a multiple of the unroll depth of 8) and as
+// few row splits as that allows; the splits are capped at 16, the depth of the consumer's prefetch.
+void size_pass(int ntiles, int rows_pad, int target_waves, int max_nw, int force_nw, int force_ns,
+               int* nsplit, int* rps, int* nw) {
+  (void)ntiles; (void)target_waves;
+  int w = std::min(8, max_nw);
+  if (force_nw == 1 || force_nw == 2 || force_nw == 4 || force_nw == 8 || force_nw == 16) w = std::min(force_nw, max_nw);
+  const int quantum = 4 * w * 8;                       // rows of one unrolled trip of a workgroup
+  int r = 2 * quantum;                                 // 16 steps per wave
+  if (ceil_div(rows_pad, r) > 16) r = round_up(ceil_div(rows_pad, 16), quantum);
+  if (force_ns > 0) r = round_up(ceil_div(rows_pad, force_ns), 64);
+  r = std::min(r, round_up(rows_pad, 64));
   *rps = r;
   *nsplit = ceil_div(rows_pad, r);
+  *nw = w;
+}
+
+int sync_both(resnmtf_handle* h) {
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return RESNMTF_OK;
+}
+
+int ensure_err_capacity(resnmtf_handle* h, int sweeps) {
+  if (sweeps <= h->err_cap) return RESNMTF_OK;
+  if (int rc = sync_both(h)) return rc;
+  if (h->err) (void)hipFree(h->err);
+  h->err = nullptr;
+  const int cap = std::max(sweeps, 1024);
+  hipError_t e = dev_alloc_zero(&h->err, (size_t)cap * h->V);
+  if (e != hipSuccess) { h->err_cap = 0; return h->fail_hip("hipMalloc err", e); }
+  h->err_cap = cap;
+  h->prepared = false;   // kernel argument blocks hold the pointer
+  return RESNMTF_OK;
 }
 
 }  // namespace
@@ -285,8 +370,6 @@ void resnmtf_default_options(resnmtf_options* o) {
   o->stream = nullptr;
   o->use_graph = 1;
   o->check_every = 8;
-  o->target_workgroups = 0;
-  o->time_kernels = 0;
 }
 
 const char* resnmtf_last_error(const resnmtf_handle* h) {
@@ -338,12 +421,16 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     vs.n = n_rows[v]; vs.m = n_cols[v]; vs.k = k[v];
     vs.NT = ceil_div(k[v], 16); vs.KP = 16 * vs.NT;
     vs.n_pad = round_up(vs.n, 64); vs.m_pad = round_up(vs.m, 64);
+    // a row pitch that is a multiple of 4 KiB puts every row of a 64-column tile on the same
+    // memory channel; one extra 256-B column block per row spreads a tile over all channels
+    auto pitch = [&](int cols_pad) { return (cols_pad % 1024 == 0 && !o.no_pitch_pad) ? cols_pad + 64 : cols_pad; };
+    vs.ldx = pitch(vs.m_pad); vs.ldxt = pitch(vs.n_pad);
     vs.owned = owned ? owned[v] != 0 : true;
     if (!vs.owned) h->all_owned = false;
+    else h->last_owned = v;
     vs.row_map.resize(n_views);
     vs.col_map.resize(n_views);
   }
-  int rc = RESNMTF_OK;
   auto bail = [&](hipError_t err, const char* what) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(err);
     resnmtf_destroy(h);
@@ -356,8 +443,8 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     h->own_stream = true;
   }
   if ((e = dev_alloc_zero(&h->ctl, 1)) != hipSuccess) return bail(e, "hipMalloc ctl");
+  h->err_cap = 1024;
   if ((e = dev_alloc_zero(&h->err, (size_t)h->err_cap * n_views)) != hipSuccess) return bail(e, "hipMalloc err");
-  if ((e = dev_alloc_zero(&h->mean_err, (size_t)h->err_cap)) != hipSuccess) return bail(e, "hipMalloc mean_err");
   for (int v = 0; v < n_views; ++v) {
     ViewState& vs = h->views[v];
     const size_t kk = (size_t)vs.k * vs.k;
@@ -368,38 +455,38 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     if ((e = dev_alloc_zero(&vs.lambda, (size_t)vs.k)) != hipSuccess) return bail(e, "hipMalloc lambda");
     if ((e = dev_alloc_zero(&vs.mu, (size_t)vs.k)) != hipSuccess) return bail(e, "hipMalloc mu");
     if ((e = dev_alloc_zero(&vs.xnorm2, 1)) != hipSuccess) return bail(e, "hipMalloc xnorm2");
-    if ((e = dev_alloc_zero(&vs.X32, (size_t)vs.n_pad * vs.m_pad)) != hipSuccess) return bail(e, "hipMalloc X32");
-    if ((e = dev_alloc_zero(&vs.Xt32, (size_t)vs.m_pad * vs.n_pad)) != hipSuccess) return bail(e, "hipMalloc Xt32");
+    if ((e = dev_alloc_zero(&vs.X32, (size_t)vs.n_pad * vs.ldx)) != hipSuccess) return bail(e, "hipMalloc X32");
+    if ((e = dev_alloc_zero(&vs.Xt32, (size_t)vs.m_pad * vs.ldxt)) != hipSuccess) return bail(e, "hipMalloc Xt32");
     if ((e = dev_alloc_zero(&vs.F32, (size_t)vs.n_pad * 64)) != hipSuccess) return bail(e, "hipMalloc F32");
     if ((e = dev_alloc_zero(&vs.G32, (size_t)vs.m_pad * 64)) != hipSuccess) return bail(e, "hipMalloc G32");
-    if ((e = dev_alloc_zero(&vs.T32, (size_t)vs.m_pad * 64)) != hipSuccess) return bail(e, "hipMalloc T32");
-    if ((e = dev_alloc_zero(&vs.FtF, kk)) != hipSuccess) return bail(e, "hipMalloc FtF");
-    if ((e = dev_alloc_zero(&vs.Ma_F, kk)) != hipSuccess) return bail(e, "hipMalloc Ma_F");
-    if ((e = dev_alloc_zero(&vs.Md_F, kk)) != hipSuccess) return bail(e, "hipMalloc Md_F");
-    const int target = o.target_workgroups > 0 ? o.target_workgroups : 1024;
-    vs.cols_total_xg = vs.n_pad + 128;
-    vs.cols_total_xtf = vs.m_pad + 64;
-    size_pass(vs.cols_total_xg / 64, vs.m_pad, target, &vs.nsplit_xg, &vs.rps_xg);
-    size_pass(vs.cols_total_xtf / 64, vs.n_pad, target, &vs.nsplit_xtf, &vs.rps_xtf);
-    if ((e = dev_alloc_zero(&vs.Pxg, (size_t)vs.nsplit_xg * vs.cols_total_xg * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Pxg");
-    if ((e = dev_alloc_zero(&vs.Pxtf, (size_t)vs.nsplit_xtf * vs.cols_total_xtf * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Pxtf");
-    const int RG = 256 / vs.KP;
-    vs.rpbF = round_up(ceil_div(vs.n, 256), RG); vs.nblkF = ceil_div(vs.n, vs.rpbF);
-    vs.rpbG = round_up(ceil_div(vs.m, 256), RG); vs.nblkG = ceil_div(vs.m, vs.rpbG);
-    if ((e = dev_alloc_zero(&vs.colsumF_part, (size_t)vs.nblkF * vs.k)) != hipSuccess) return bail(e, "hipMalloc colsumF");
-    if ((e = dev_alloc_zero(&vs.colsumG_part, (size_t)vs.nblkG * vs.k)) != hipSuccess) return bail(e, "hipMalloc colsumG");
+    for (double** pp : {&vs.FtF, &vs.FtFS, &vs.Ma_F, &vs.Md_F, &vs.Ma_G, &vs.Md_G})
+      if ((e = dev_alloc_zero(pp, kk)) != hipSuccess) return bail(e, "hipMalloc kxk");
+    if ((e = dev_alloc_zero(&vs.cF, (size_t)vs.k)) != hipSuccess) return bail(e, "hipMalloc cF");
+    // target_workgroups is kept as the tuning knob's name; it counts WAVES of a streaming pass
+    const int target = o.target_workgroups > 0 ? o.target_workgroups : 4096;
+    size_pass(vs.n_pad / 64, vs.m_pad, target, max_pass_waves(vs.NT), o.pass_waves, o.pass_splits_xg,
+              &vs.nsplit_xg, &vs.rps_xg, &vs.nw_xg);
+    size_pass(vs.m_pad / 64, vs.n_pad, target, max_pass_waves(vs.NT), o.pass_waves, o.pass_splits_xtf,
+              &vs.nsplit_xtf, &vs.rps_xtf, &vs.nw_xtf);
+    if ((e = dev_alloc_zero(&vs.Pxg, (size_t)vs.nsplit_xg * vs.n_pad * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Pxg");
+    if ((e = dev_alloc_zero(&vs.Pxtf, (size_t)vs.nsplit_xtf * vs.m_pad * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Pxtf");
+    const int RG = UPDATE_THREADS / vs.KP;
+    // one row group per update workgroup up to 256 workgroups: a single memory round trip per
+    // workgroup, and few enough partials that the k x k jobs sum them in a handful of load batches
+    const int nblk_target = o.update_blocks > 0 ? o.update_blocks : 256;
+    vs.rpbF = round_up(std::max(RG, ceil_div(vs.n, nblk_target)), RG); vs.nblkF = ceil_div(vs.n, vs.rpbF);
+    vs.rpbG = round_up(std::max(RG, ceil_div(vs.m, nblk_target)), RG); vs.nblkG = ceil_div(vs.m, vs.rpbG);
+    const size_t kkp = (size_t)vs.KP * vs.KP;
+    if ((e = dev_alloc_zero(&vs.partF, (size_t)vs.nblkF * (kkp + vs.KP))) != hipSuccess) return bail(e, "hipMalloc partF");
+    if ((e = dev_alloc_zero(&vs.partG, (size_t)vs.nblkG * (2 * kkp + vs.KP))) != hipSuccess) return bail(e, "hipMalloc partG");
   }
-  if ((e = set_smem_attrs<16>()) != hipSuccess) return bail(e, "hipFuncSetAttribute");
-  if ((e = set_smem_attrs<32>()) != hipSuccess) return bail(e, "hipFuncSetAttribute");
-  if ((e = set_smem_attrs<48>()) != hipSuccess) return bail(e, "hipFuncSetAttribute");
-  if ((e = set_smem_attrs<64>()) != hipSuccess) return bail(e, "hipFuncSetAttribute");
+  if ((e = set_all_attrs()) != hipSuccess) return bail(e, "hipFuncSetAttribute");
   if (o.time_kernels) {
     h->ev.resize(8192);
     h->ev_kind.resize(4096);
     for (auto& evt : h->ev)
       if ((e = hipEventCreate(&evt)) != hipSuccess) return bail(e, "hipEventCreate");
   }
-  (void)rc;
   *out = h;
   return RESNMTF_OK;
 }
@@ -412,7 +499,6 @@ int resnmtf_destroy(resnmtf_handle* h) {
   for (auto& v : h->views) free_view(v);
   if (h->ctl) (void)hipFree(h->ctl);
   if (h->err) (void)hipFree(h->err);
-  if (h->mean_err) (void)hipFree(h->mean_err);
   for (auto& evt : h->ev)
     if (evt) (void)hipEventDestroy(evt);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -426,6 +512,7 @@ int resnmtf_set_view(resnmtf_handle* h, int v, const double* x) {
   ViewState& vs = h->views[v];
   if (!vs.owned) return h->fail(RESNMTF_ERR_STATE, "set_view on a view this handle does not own");
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
+  if (int rc = sync_both(h)) return rc;
   const size_t count = (size_t)vs.n * vs.m;
   double* staging = nullptr;
   double* partial = nullptr;
@@ -435,11 +522,11 @@ int resnmtf_set_view(resnmtf_handle* h, int v, const double* x) {
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&partial), (size_t)nparts * sizeof(double));
   if (e != hipSuccess) { (void)hipFree(staging); return h->fail_hip("hipMalloc partial", e); }
   e = hipMemcpyAsync(staging, x, count * sizeof(double), hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(vs.X32, 0, (size_t)vs.n_pad * vs.m_pad * sizeof(float), h->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(vs.Xt32, 0, (size_t)vs.m_pad * vs.n_pad * sizeof(float), h->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(vs.X32, 0, (size_t)vs.n_pad * vs.ldx * sizeof(float), h->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(vs.Xt32, 0, (size_t)vs.m_pad * vs.ldxt * sizeof(float), h->stream);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(convert_x_kernel, grid, dim3(256), 0, h->stream, staging, vs.n, vs.m, vs.X32, vs.m_pad,
-                       vs.Xt32, vs.n_pad, partial);
+    hipLaunchKernelGGL(convert_x_kernel, grid, dim3(256), 0, h->stream, staging, vs.n, vs.m, vs.X32, vs.ldx,
+                       vs.Xt32, vs.ldxt, partial);
     hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, h->stream, partial, nparts, vs.xnorm2);
     e = hipGetLastError();
   }
@@ -457,6 +544,7 @@ int resnmtf_set_factors(resnmtf_handle* h, int v, const double* F, const double*
   if (!F || !S || !G) return h->fail(RESNMTF_ERR_INVALID, "F, S and G are required");
   ViewState& vs = h->views[v];
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
+  if (int rc = sync_both(h)) return rc;
   std::vector<double> f, s, g;
   to_row_major(F, vs.n, vs.k, f);
   to_row_major(S, vs.k, vs.k, s);
@@ -477,7 +565,6 @@ int resnmtf_set_factors(resnmtf_handle* h, int v, const double* F, const double*
     HIP_TRY(h, hipMemcpyAsync(vs.mu, muv.data(), muv.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(vs.F32, 0, (size_t)vs.n_pad * 64 * sizeof(float), h->stream));
     HIP_TRY(h, hipMemsetAsync(vs.G32, 0, (size_t)vs.m_pad * 64 * sizeof(float), h->stream));
-    HIP_TRY(h, hipMemsetAsync(vs.T32, 0, (size_t)vs.m_pad * 64 * sizeof(float), h->stream));
     hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(vs.n * vs.k, 256)), dim3(256), 0, h->stream, vs.F, vs.n,
                        vs.k, vs.F32);
     hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(vs.m * vs.k, 256)), dim3(256), 0, h->stream, vs.G, vs.m,
@@ -555,20 +642,20 @@ static int build_args(resnmtf_handle* h) {
     if (!vs.has_x) return h->fail(RESNMTF_ERR_STATE, "set_view missing for an owned view");
     // --- streaming passes
     PassArgs& xg = vs.passXG;
-    xg.A0 = vs.Xt32; xg.lda0 = vs.n_pad; xg.ntiles0 = vs.n_pad / 64;
-    xg.A1 = vs.G32; xg.A2 = vs.T32; xg.B = vs.G32; xg.P = vs.Pxg;
-    xg.cols_total = vs.cols_total_xg; xg.rows_pad = vs.m_pad; xg.rows_per_split = vs.rps_xg; xg.ctl = h->ctl;
+    xg = PassArgs{};
+    xg.A = vs.Xt32; xg.lda = vs.ldxt; xg.ntiles = vs.n_pad / 64; xg.B = vs.G32; xg.P = vs.Pxg;
+    xg.cols_pad = vs.n_pad; xg.rows_pad = vs.m_pad; xg.rows_per_split = vs.rps_xg; xg.ctl = h->ctl;
     PassArgs& xt = vs.passXtF;
-    xt.A0 = vs.X32; xt.lda0 = vs.m_pad; xt.ntiles0 = vs.m_pad / 64;
-    xt.A1 = vs.F32; xt.A2 = nullptr; xt.B = vs.F32; xt.P = vs.Pxtf;
-    xt.cols_total = vs.cols_total_xtf; xt.rows_pad = vs.n_pad; xt.rows_per_split = vs.rps_xtf; xt.ctl = h->ctl;
+    xt = PassArgs{};
+    xt.A = vs.X32; xt.lda = vs.ldx; xt.ntiles = vs.m_pad / 64; xt.B = vs.F32; xt.P = vs.Pxtf;
+    xt.cols_pad = vs.m_pad; xt.rows_pad = vs.n_pad; xt.rows_per_split = vs.rps_xtf; xt.ctl = h->ctl;
     // --- F update (R/update_steps.r:141-165)
     UpdateArgs& f = vs.argF;
     f = UpdateArgs{};
-    f.len = vs.n; f.k = vs.k; f.W = vs.F; f.W32 = vs.F32; f.T32 = nullptr;
-    f.P = vs.Pxg; f.nsplit = vs.nsplit_xg; f.cols_total = vs.cols_total_xg; f.gram_col0 = 0;
-    f.Ma_in = vs.Ma_F; f.Md_in = vs.Md_F; f.S = vs.S; f.lm = vs.lambda; f.gram_out = nullptr;
-    f.colsum_part = vs.colsumF_part; f.rows_per_block = vs.rpbF; f.ctl = h->ctl;
+    f.len = vs.n; f.k = vs.k; f.W = vs.F; f.W32 = vs.F32;
+    f.P = vs.Pxg; f.nsplit = vs.nsplit_xg; f.cols_pad = vs.n_pad;
+    f.Ma = vs.Ma_F; f.Md = vs.Md_F; f.lm = vs.lambda; f.part = vs.partF;
+    f.rows_per_block = vs.rpbF; f.ctl = h->ctl;
     {
       double sigma = 0.0;
       for (int i = 0; i < V; ++i) sigma += h->phi[(size_t)i + (size_t)v * V];     // sum(phi[, v])  (:150,:152)
@@ -588,10 +675,10 @@ static int build_args(resnmtf_handle* h) {
     // --- G update (R/update_steps.r:180-207); branch on the WHOLE psi matrix (:190)
     UpdateArgs& g = vs.argG;
     g = UpdateArgs{};
-    g.len = vs.m; g.k = vs.k; g.W = vs.G; g.W32 = vs.G32; g.T32 = vs.T32;
-    g.P = vs.Pxtf; g.nsplit = vs.nsplit_xtf; g.cols_total = vs.cols_total_xtf; g.gram_col0 = vs.m_pad;
-    g.Ma_in = nullptr; g.Md_in = nullptr; g.S = vs.S; g.lm = vs.mu; g.gram_out = vs.FtF;
-    g.colsum_part = vs.colsumG_part; g.rows_per_block = vs.rpbG; g.ctl = h->ctl;
+    g.len = vs.m; g.k = vs.k; g.W = vs.G; g.W32 = vs.G32;
+    g.P = vs.Pxtf; g.nsplit = vs.nsplit_xtf; g.cols_pad = vs.m_pad;
+    g.Ma = vs.Ma_G; g.Md = vs.Md_G; g.lm = vs.mu; g.part = vs.partG;
+    g.rows_per_block = vs.rpbG; g.ctl = h->ctl;
     {
       double sigma = 0.0;
       for (int i = 0; i < V; ++i) sigma += h->psi[(size_t)i + (size_t)v * V];     // sum(psi[, v])  (:195,:200)
@@ -608,32 +695,45 @@ static int build_args(resnmtf_handle* h) {
         c.W = h->views[i].G; c.map = mp.dev; c.weight = wgt; c.n_other = (double)h->views[i].m;
       }
     }
-    // --- S update (R/update_steps.r:220-240); branch on the WHOLE xi matrix (:226)
-    SArgs& s = vs.argS;
-    s = SArgs{};
-    s.k = vs.k; s.mode = 1;
-    s.Pxg = vs.Pxg; s.nsplit_xg = vs.nsplit_xg; s.cols_total_xg = vs.cols_total_xg;
-    s.gram_col0 = vs.n_pad; s.cross_col0 = vs.n_pad + 64;
-    s.FtF = vs.FtF; s.S = vs.S; s.lambda = vs.lambda; s.mu = vs.mu;
-    s.colsumF_part = vs.colsumF_part; s.nblkF = vs.nblkF; s.colsumG_part = vs.colsumG_part; s.nblkG = vs.nblkG;
-    s.Ma_F = vs.Ma_F; s.Md_F = vs.Md_F; s.xnorm2 = vs.xnorm2;
-    s.err = h->err; s.err_stride = V; s.err_col = v; s.err_cap = h->err_cap; s.ctl = h->ctl;
+    vs.argGram = g;            // same geometry; the GRAM_ONLY instantiation ignores the update inputs
+    vs.argGram.restricted = 0; vs.argGram.n_couple = 0;
+    // --- k x k side kernels
+    KKFArgs& kf = vs.argKF;
+    kf = KKFArgs{};
+    kf.k = vs.k; kf.part = vs.partF; kf.nblk = vs.nblkF; kf.S = vs.S;
+    kf.FtF = vs.FtF; kf.FtFS = vs.FtFS; kf.Ma_G = vs.Ma_G; kf.Md_G = vs.Md_G; kf.cF = vs.cF; kf.ctl = h->ctl;
+    KKSArgs& ks = vs.argKS;
+    ks = KKSArgs{};
+    ks.k = vs.k; ks.mode = 1; ks.part = vs.partG; ks.nblk = vs.nblkG;
+    ks.FtF = vs.FtF; ks.FtFS = vs.FtFS; ks.cF = vs.cF;
+    ks.S = vs.S; ks.lambda = vs.lambda; ks.mu = vs.mu; ks.Ma_F = vs.Ma_F; ks.Md_F = vs.Md_F;
+    ks.xnorm2 = vs.xnorm2;
+    ks.err = h->err; ks.err_stride = V; ks.err_col = v; ks.err_cap = h->err_cap;
+    ks.ctl = h->ctl; ks.last_view = (v == h->last_owned) ? 1 : 0; ks.n_views = V; ks.tol = -1.0;
     {
       double sigma = 0.0;
       for (int i = 0; i < V; ++i) sigma += h->xi[(size_t)i + (size_t)v * V];      // sum(xi[, v])  (:231,:233)
-      s.restricted = (sum_xi != 0.0) ? 1 : 0;
-      s.sigma = sigma;
-      s.n_couple = 0;
-      for (int i = 0; i < V && s.restricted; ++i) {
+      ks.restricted = (sum_xi != 0.0) ? 1 : 0;                                     // whole matrix (:226)
+      ks.sigma = sigma;
+      ks.n_couple = 0;
+      for (int i = 0; i < V && ks.restricted; ++i) {
         const double wgt = h->xi[(size_t)i + (size_t)v * V];
         if (wgt == 0.0 || i == v) continue;                                        // utils.r:42
         if (h->views[i].k != vs.k) return h->fail(RESNMTF_ERR_INVALID, "xi-coupled views need equal k");
-        SCouple& c = s.couple[s.n_couple++];
-        c.S = h->views[i].S; c.weight = wgt;
+        SCouple& c = ks.couple[ks.n_couple++];
+        c.S = h->views[i].S;      // running list: updated in place, in view order, on the side stream
+        c.weight = wgt;
       }
     }
   }
   return RESNMTF_OK;
+}
+
+int resnmtf_reserve_sweeps(resnmtf_handle* h, int sweeps) {
+  if (!h) return RESNMTF_ERR_INVALID;
+  if (sweeps < 1) return h->fail(RESNMTF_ERR_INVALID, "sweeps must be positive");
+  HIP_TRY(h, hipSetDevice(h->opt.device_id));
+  return ensure_err_capacity(h, sweeps);
 }
 
 int resnmtf_prepare(resnmtf_handle* h) {
@@ -644,15 +744,12 @@ int resnmtf_prepare(resnmtf_handle* h) {
     if (int rc = build_args(h)) return rc;
     h->prepared = true;
   }
-  // run prologue: the first X.G pass and the F coefficients of every owned view
+  // run prologue: reset the loop control, F coefficients and the first X.G pass of every owned view
+  if (int rc = sync_both(h)) return rc;
   SweepCtl zero{};
-  HIP_TRY(h, hipMemcpyAsync(h->ctl, &zero, sizeof(zero), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));   // `zero` is a stack object
-  for (const auto& v : h->views) {
-    if (!v.owned) continue;
-    launch_pass(h, v, true);
-    launch_s(h, v, 0, 0, false);
-  }
+  HIP_TRY(h, hipMemcpy(h->ctl, &zero, sizeof(zero), hipMemcpyHostToDevice));
+  for (const auto& v : h->views)
+    if (v.owned) enqueue_prologue(h, v);
   HIP_TRY(h, hipGetLastError());
   return RESNMTF_OK;
 }
@@ -663,11 +760,12 @@ int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep) {
   const ViewState& vs = h->views[v];
   if (!vs.owned) return h->fail(RESNMTF_ERR_STATE, "phase on a view this handle does not own");
   if (sweep < 0) return h->fail(RESNMTF_ERR_INVALID, "negative sweep index");
+  if (sweep >= h->err_cap) return h->fail(RESNMTF_ERR_STATE, "sweep beyond the reserved error buffer (resnmtf_reserve_sweeps)");
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
   switch (phase) {
-    case RESNMTF_PHASE_F: enqueue_phase_f(h, vs); break;
-    case RESNMTF_PHASE_G: enqueue_phase_g(h, vs); break;
-    case RESNMTF_PHASE_S: enqueue_phase_s(h, vs, sweep, false); break;
+    case RESNMTF_PHASE_F: enqueue_phase_f(h, vs, false); break;
+    case RESNMTF_PHASE_G: enqueue_phase_g(h, vs, -1.0, false); break;
+    case RESNMTF_PHASE_S: break;   // S is complete behind PHASE_G on the handle's stream
     default: return h->fail(RESNMTF_ERR_INVALID, "unknown phase");
   }
   HIP_TRY(h, hipGetLastError());
@@ -680,6 +778,7 @@ int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, doubl
   if (iters_done) *iters_done = 0;
   if (!h->all_owned) return h->fail(RESNMTF_ERR_STATE, "resnmtf_run needs a handle that owns every view; use the phase API");
   if (n_iters < 0) return h->fail(RESNMTF_ERR_INVALID, "n_iters must be >= 0");
+  HIP_TRY(h, hipSetDevice(h->opt.device_id));
   int total;
   double tol_arg;
   if (n_iters > 0) {
@@ -692,6 +791,7 @@ int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, doubl
     if (all_err) total = std::min(total, err_capacity);
     if (total < 1) return h->fail(RESNMTF_ERR_INVALID, "convergence mode needs max_iters > 0 or an all_err buffer");
   }
+  if (int rc = ensure_err_capacity(h, total)) return rc;
   if (int rc = resnmtf_prepare(h)) return rc;
   const bool eager = !h->opt.use_graph || h->opt.time_kernels;
   const int batch = std::max(1, h->opt.check_every);
@@ -702,46 +802,42 @@ int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, doubl
     h->graph_multi_sweeps = batch;
     h->graph_tol = tol_arg;
   }
-  int done_total = 0;
-  bool converged = false;
-  std::vector<double> host_err;
-  while (done_total < total && !converged) {
-    const int chunk = std::min(total - done_total, h->err_cap);
-    // restart the chunk-local sweep counter, keep prev_mean / done
-    int zero = 0;
-    HIP_TRY(h, hipMemcpyAsync(&h->ctl->sweep, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    int enq = 0;
-    SweepCtl host_ctl{};
-    while (enq < chunk) {
-      int todo = std::min(batch, chunk - enq);
-      if (eager) {
-        for (int s = 0; s < todo; ++s) {
-          enqueue_sweep(h, tol_arg);
-          if (h->opt.time_kernels && h->ev_used + 8 * (size_t)h->V > h->ev.size())
-            if (int rc = flush_timing(h)) return rc;
-        }
-      } else if (todo == h->graph_multi_sweeps) {
-        HIP_TRY(h, hipGraphLaunch(h->graph_multi, h->stream));
-      } else {
-        for (int s = 0; s < todo; ++s) HIP_TRY(h, hipGraphLaunch(h->graph_one, h->stream));
+  SweepCtl host_ctl{};
+  int enq = 0;
+  while (enq < total) {
+    const int todo = std::min(batch, total - enq);
+    if (eager) {
+      for (int s = 0; s < todo; ++s) {
+        enqueue_sweep(h, tol_arg);
+        if (h->opt.time_kernels && h->ev_used + 8 * (size_t)h->V > h->ev.size())
+          if (int rc = flush_timing(h)) return rc;
       }
-      enq += todo;
-      if (tol_arg >= 0.0) {   // convergence mode: host check between batches
-        HIP_TRY(h, hipMemcpyAsync(&host_ctl, h->ctl, sizeof(SweepCtl), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        if (host_ctl.done) { converged = true; break; }
-      }
+    } else if (todo == h->graph_multi_sweeps) {
+      HIP_TRY(h, hipGraphLaunch(h->graph_multi, h->stream));
+    } else {
+      for (int s = 0; s < todo; ++s) HIP_TRY(h, hipGraphLaunch(h->graph_one, h->stream));
     }
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(&host_ctl, h->ctl, sizeof(SweepCtl), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    const int done_chunk = host_ctl.sweep;
-    if (all_err && done_chunk > 0)
-      HIP_TRY(h, hipMemcpy(all_err + done_total, h->mean_err, (size_t)done_chunk * sizeof(double), hipMemcpyDeviceToHost));
-    done_total += done_chunk;
-    if (host_ctl.done) converged = true;
-    if (done_chunk < chunk && !converged) return h->fail(RESNMTF_ERR_HIP, "sweep counter mismatch");
+    enq += todo;
+    if (tol_arg >= 0.0) {     // convergence mode (R/main.r:50-81): look at the device flag between batches
+      HIP_TRY(h, hipGetLastError());
+      if (int rc = sync_both(h)) return rc;
+      HIP_TRY(h, hipMemcpy(&host_ctl, h->ctl, sizeof(SweepCtl), hipMemcpyDeviceToHost));
+      if (host_ctl.done) break;
+    }
+  }
+  HIP_TRY(h, hipGetLastError());
+  if (int rc = sync_both(h)) return rc;
+  HIP_TRY(h, hipMemcpy(&host_ctl, h->ctl, sizeof(SweepCtl), hipMemcpyDeviceToHost));
+  const int done_total = host_ctl.sweep;
+  if (tol_arg < 0.0 && done_total != total) return h->fail(RESNMTF_ERR_HIP, "sweep counter mismatch");
+  if (all_err && done_total > 0) {
+    std::vector<double> host_err((size_t)done_total * h->V);
+    HIP_TRY(h, hipMemcpy(host_err.data(), h->err, host_err.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int t = 0; t < done_total; ++t) {        // mean over views (R/main.r:77-78,104-107)
+      double sum = 0.0;
+      for (int v = 0; v < h->V; ++v) sum += host_err[(size_t)t * h->V + v];
+      all_err[t] = sum / (double)h->V;
+    }
   }
   if (h->opt.time_kernels)
     if (int rc = flush_timing(h)) return rc;
@@ -753,7 +849,7 @@ int resnmtf_get_factors(resnmtf_handle* h, int v, double* F, double* S, double* 
   if (int rc = check_view(h, v)) return rc;
   ViewState& vs = h->views[v];
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (int rc = sync_both(h)) return rc;
   std::vector<double> tmp;
   if (F) { tmp.resize((size_t)vs.n * vs.k); HIP_TRY(h, hipMemcpy(tmp.data(), vs.F, tmp.size() * sizeof(double), hipMemcpyDeviceToHost)); to_col_major(tmp, vs.n, vs.k, F); }
   if (S) { tmp.resize((size_t)vs.k * vs.k); HIP_TRY(h, hipMemcpy(tmp.data(), vs.S, tmp.size() * sizeof(double), hipMemcpyDeviceToHost)); to_col_major(tmp, vs.k, vs.k, S); }
@@ -771,6 +867,7 @@ int resnmtf_finalise(resnmtf_handle* h, int v, double* F, double* S, double* G, 
   if (int rc = check_view(h, v)) return rc;
   ViewState& vs = h->views[v];
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
+  if (int rc = sync_both(h)) return rc;
   const size_t nk = (size_t)vs.n * vs.k, mk = (size_t)vs.m * vs.k, kk = (size_t)vs.k * vs.k;
   double* buf = nullptr;   // [cF k][cG k][S kk][Fout nk][rc nk][Gout mk][cc mk]
   int* rel = nullptr;
@@ -815,21 +912,28 @@ int resnmtf_factor_device_ptr(resnmtf_handle* h, int v, int which, void** ptr, s
 int resnmtf_view_errors(resnmtf_handle* h, int v, int first, int count, double* out) {
   if (int rc = check_view(h, v)) return rc;
   if (!out || first < 0 || count < 0) return h->fail(RESNMTF_ERR_INVALID, "bad error range");
-  if (count > h->err_cap) return h->fail(RESNMTF_ERR_INVALID, "range longer than the error ring");
+  if (first + count > h->err_cap) return h->fail(RESNMTF_ERR_INVALID, "range beyond the reserved error buffer");
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  std::vector<double> ring((size_t)h->err_cap * h->V);
-  HIP_TRY(h, hipMemcpy(ring.data(), h->err, ring.size() * sizeof(double), hipMemcpyDeviceToHost));
-  for (int t = 0; t < count; ++t) out[t] = ring[(size_t)((first + t) % h->err_cap) * h->V + v];
+  if (int rc = sync_both(h)) return rc;
+  std::vector<double> buf((size_t)count * h->V);
+  if (count > 0)
+    HIP_TRY(h, hipMemcpy(buf.data(), h->err + (size_t)first * h->V, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int t = 0; t < count; ++t) out[t] = buf[(size_t)t * h->V + v];
   return RESNMTF_OK;
 }
 
 int resnmtf_synchronize(resnmtf_handle* h) {
   if (!h) return RESNMTF_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  return RESNMTF_OK;
+  return sync_both(h);
 }
+
+#ifdef RESNMTF_STAMPS
+// diagnostic build only: point the stamp buffer at `buf` ([blocks][16] u64) or detach it (NULL)
+int resnmtf_debug_set_stamp_buffer(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : RESNMTF_ERR_HIP;
+}
+#endif
 
 int resnmtf_pass_timings(resnmtf_handle* h, resnmtf_pass_timing* out, int reset) {
   if (!h || !out) return RESNMTF_ERR_INVALID;

@@ -38,7 +38,8 @@ class Engine:
     def __init__(self, n_rows: Sequence[int], n_cols: Sequence[int], k: Sequence[int],
                  owned: Optional[Sequence[bool]] = None, device_id: int = 0, stream: int = 0,
                  use_graph: bool = True, check_every: int = 8, target_workgroups: int = 0,
-                 time_kernels: bool = False):
+                 time_kernels: bool = False, pass_waves: int = 0, pass_splits_xg: int = 0,
+                 pass_splits_xtf: int = 0, pass_lds_pad_kb: int = 0, update_blocks: int = 0, no_pitch_pad: bool = False):
         self._lib = _lib.load()
         self.n_views = len(n_rows)
         self.n_rows = [int(x) for x in n_rows]
@@ -53,6 +54,12 @@ class Engine:
         opts.check_every = int(check_every)
         opts.target_workgroups = int(target_workgroups)
         opts.time_kernels = 1 if time_kernels else 0
+        opts.pass_waves = int(pass_waves)
+        opts.pass_splits_xg = int(pass_splits_xg)
+        opts.pass_splits_xtf = int(pass_splits_xtf)
+        opts.pass_lds_pad_kb = int(pass_lds_pad_kb)
+        opts.update_blocks = int(update_blocks)
+        opts.no_pitch_pad = 1 if no_pitch_pad else 0
         nr = np.asarray(self.n_rows, dtype=np.int32)
         nc = np.asarray(self.n_cols, dtype=np.int32)
         kk = np.asarray(self.k, dtype=np.int32)
@@ -136,6 +143,9 @@ class Engine:
         self._check(self._lib.resnmtf_run(self._h, int(n_iters or 0), float(tol), int(max_iters), _dp(errs), cap,
                                           C.byref(done)))
         return errs[:done.value].copy()
+
+    def reserve_sweeps(self, sweeps: int):
+        self._check(self._lib.resnmtf_reserve_sweeps(self._h, int(sweeps)))
 
     def prepare(self):
         self._check(self._lib.resnmtf_prepare(self._h))
