@@ -72,6 +72,8 @@ def run_single(args) -> dict:
     k = prob.k
 
     def make_engine(**kw):
+        if os.environ.get("RESNMTF_NO_GRAPH") == "1":      # profiling runs: plain launches, one row per dispatch
+            kw.setdefault("use_graph", False)
         e = Engine([n], [m], [k], device_id=0, **kw)
         t0 = time.perf_counter()
         e.set_view(0, prob.data[0])
@@ -144,7 +146,10 @@ def run_sharded(args) -> dict:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
-    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                            device_id=torch.device("cuda", local_rank))
     n_views = world
     n, m, k = 10000, 2000, 16
     # every rank builds only the view it owns (same seeds as synth.make_problem) + all initial factors
@@ -184,7 +189,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
-    out = run_single(args) if args.gpus == 1 else run_sharded(args)
+    # RESNMTF_FORCE_SHARDED=1 exercises the multi-rank code path (nccl init, ordered exchange driver,
+    # barrier/max timing) with a single rank -- a rehearsal on the one-GPU box
+    sharded_path = args.gpus > 1 or os.environ.get("RESNMTF_FORCE_SHARDED") == "1"
+    out = run_sharded(args) if sharded_path else run_single(args)
     if out:
         print(json.dumps(out), flush=True)
 

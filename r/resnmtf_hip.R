@@ -1,0 +1,68 @@
+# r/resnmtf_hip.R -- R-side wrapper that keeps res_nmtf_inner()'s signature (R/main.r:32-37) and
+# hands the loop (R/main.r:49-109), normalisation_check (R/main.r:110) and the binary cluster
+# matrices (R/obtain_bicl.r:162-180) to libresnmtf_hip.so through r/shim.c.
+#
+# UNTESTED: no R interpreter is available where this repository is built or run.  The tested
+# stand-in with the same call sequence is resnmtf_amd/api.py::res_nmtf_inner.
+#
+# Everything else of the package is unchanged: apply_resnmtf() (naming, reorder_data,
+# init_rest_mats, check_inputs), spurious-bicluster removal, bisilhouette and stability selection
+# keep calling res_nmtf_inner() and receive the same list fields.
+
+# shared names (character vectors or NA, as produced by produce_indices, R/utils.r:560-601)
+# -> 1-based index pairs cbind(idx_v, idx_w); NULL stands for NA
+name_maps <- function(indices, names_list) {
+  n_v <- length(names_list)
+  lapply(seq_len(n_v), function(v) {
+    lapply(seq_len(n_v), function(w) {
+      if (w == v) return(NULL)
+      shared <- indices[[v]][[as.character(w)]]
+      if (any(is.na(shared))) return(NULL)
+      cbind(match(shared, names_list[[v]]), match(shared, names_list[[w]]))
+    })
+  })
+}
+
+res_nmtf_inner_hip <- function(
+    data, row_indices, column_indices,
+    init_f = NULL, init_s = NULL, init_g = NULL,
+    k_vec = NULL, phi = NULL, xi = NULL, psi = NULL,
+    n_iters = NULL, num_repeats = 5, spurious = TRUE, distance = "euclidean",
+    no_clusts = FALSE, max_iters = 100000L) {
+  n_v <- length(data)
+  # initial factors exactly as the reference builds them (SVD + noise, or the explicit branch)
+  initial_mats <- init_mats(data, n_v, k_vec, init_f, init_g, init_s)        # R/update_steps.r:36-66
+  row_maps <- name_maps(row_indices, lapply(data, rownames))
+  col_maps <- name_maps(column_indices, lapply(data, colnames))
+  res <- .Call("resnmtf_hip_inner", data, initial_mats$current_f, initial_mats$current_s,
+               initial_mats$current_g, phi, xi, psi, row_maps, col_maps,
+               as.integer(ifelse(is.null(n_iters), 0L, n_iters)), as.integer(max_iters))
+  for (v in seq_len(n_v)) {                                                  # R/update_steps.r:57-60
+    rownames(res$output_f[[v]]) <- rownames(data[[v]])
+    rownames(res$output_g[[v]]) <- colnames(data[[v]])
+    rownames(res$row_clusters[[v]]) <- rownames(data[[v]])                   # R/obtain_bicl.r:166,171
+    rownames(res$col_clusters[[v]]) <- colnames(data[[v]])
+  }
+  if (no_clusts) {                                                           # R/main.r:115-120
+    return(list(output_f = res$output_f, output_s = res$output_s, output_g = res$output_g))
+  }
+  row_cl <- res$row_clusters
+  col_cl <- res$col_clusters
+  bisil <- c()
+  biclusts <- if (spurious) check_biclusters(data, res$output_f, num_repeats) else NULL   # stays in R
+  for (i in seq_len(n_v)) {                                                  # R/obtain_bicl.r:178-196
+    relations <- apply(res$output_s[[i]], 2, which.max)
+    if (spurious) {
+      indices <- ((biclusts$score[i, ]) < biclusts$max_threshold[i]) | ((biclusts$score[i, ]) == 0)
+      new_indices <- indices[relations]
+      row_cl[[i]][, new_indices] <- 0
+      col_cl[[i]][, new_indices] <- 0
+    }
+    bisil <- c(bisil, bisilhouette::bisilhouette(data[[i]], row_cl[[i]], col_cl[[i]], method = distance)$bisil)
+  }
+  bisil <- ifelse(sum(bisil) == 0, 0, mean(bisil[bisil != 0]))
+  error <- if (is.null(n_iters)) mean(utils::tail(res$All_Error, n = 10)) else utils::tail(res$All_Error, n = 1)
+  list(output_f = res$output_f, output_s = res$output_s, output_g = res$output_g,
+       Error = error, All_Error = res$All_Error, bisil = bisil,
+       row_clusters = row_cl, col_clusters = col_cl, lambda = res$lambda, mu = res$mu)
+}

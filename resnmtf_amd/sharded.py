@@ -1,0 +1,271 @@
+"""View-sharded sweep: one process per GPU, views placed on ranks, coupled factor blocks
+exchanged through ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU node, "gloo"
+in the CPU tests) in the reference's Gauss-Seidel order.
+
+The reference updates views strictly in index order inside a sweep and every coupling term reads
+the RUNNING lists (``R/update_steps.r:282-314``): view v sees this sweep's F/G/S of views w < v and
+the previous sweep's of views w > v.  A one-shot all-gather would change that (Jacobi), so the
+exchange is a sequence of ordered broadcasts, one per (view, factor) that some other rank reads:
+
+    for v in views:                      # every rank walks the same list
+        owner(v): PHASE_F(v)             # update_f
+        broadcast F_v        if another rank's view is phi-coupled to v through shared rows
+        owner(v): PHASE_G(v)             # Xt.F pass, update_g, X.G pass (+ update_s, update_lm, error)
+        broadcast G_v        if psi-coupled through shared columns
+        broadcast S_v        if xi-coupled
+
+Only the small factor blocks (n x k, m x k, k x k) travel; the streaming passes over X -- all
+of the HBM traffic -- touch own-view data only.  Uncoupled views need no exchange at all.
+
+The engine is injected (``engine`` argument) so that the identical driver code runs in the CPU
+tests on a stand-in engine; in production it is ``resnmtf_amd.engine.Engine`` and every kernel
+and every broadcast is enqueued on torch's current HIP stream.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import naming
+from ._lib import FACTOR_F, FACTOR_G, FACTOR_S, PHASE_F, PHASE_G, PHASE_S
+from .synth import Problem, planted_view, random_init
+
+_WHICH = {"F": FACTOR_F, "G": FACTOR_G, "S": FACTOR_S}
+
+
+def exchange_plan(n_views: int, owner_of: Sequence[int], phi, xi, psi, row_shared, col_shared) -> List[Dict[str, bool]]:
+    """For every view, which of its factors some OTHER rank reads (identical on every rank).
+
+    F_v is read by view w when phi[v, w] != 0 and w has a shared-row map towards v that is not NA
+    (``R/utils.r:66-71``); likewise G_v through psi / shared columns; S_v when xi[v, w] != 0
+    (``R/utils.r:42``).  A factor travels only if such a w lives on a rank other than v's owner."""
+    phi = np.asarray(phi); xi = np.asarray(xi); psi = np.asarray(psi)
+    plan = []
+    for v in range(n_views):
+        need = {"F": False, "G": False, "S": False}
+        for w in range(n_views):
+            if w == v or owner_of[w] == owner_of[v]:
+                continue
+            if phi[v, w] != 0 and row_shared[w].get(v) is not None:
+                need["F"] = True
+            if psi[v, w] != 0 and col_shared[w].get(v) is not None:
+                need["G"] = True
+            if xi[v, w] != 0:
+                need["S"] = True
+        plan.append(need)
+    return plan
+
+
+class _CudaBlob:
+    """Exposes a raw device range through ``__cuda_array_interface__`` so that torch can alias it."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+class HipEngineAdapter:
+    """What the driver needs from an engine, on top of ``resnmtf_amd.engine.Engine``."""
+
+    def __init__(self, engine):
+        self.e = engine
+        self._views: Dict[tuple, object] = {}
+
+    def reserve_sweeps(self, n):
+        self.e.reserve_sweeps(n)
+
+    def prepare(self):
+        self.e.prepare()
+
+    def phase(self, v, ph, sweep):
+        self.e.phase(v, ph, sweep)
+
+    def factor_tensor(self, v: int, which: str):
+        import torch
+        key = (v, which)
+        if key not in self._views:
+            ptr, nbytes = self.e.factor_device_ptr(v, _WHICH[which])
+            self._views[key] = torch.as_tensor(_CudaBlob(ptr, nbytes // 8), device="cuda")
+        return self._views[key]
+
+    def synchronize(self):
+        self.e.synchronize()
+
+    def view_errors(self, v, first, count):
+        return self.e.view_errors(v, first, count)
+
+    def finalise(self, v):
+        return self.e.finalise(v)
+
+    def get_factors(self, v):
+        return self.e.get_factors(v)
+
+    def close(self):
+        self._views.clear()
+        self.e.close()
+
+
+def make_hip_engine(prob: Problem, owned: Sequence[bool], device_index: int, stream: int,
+                    **engine_opts) -> HipEngineAdapter:
+    """Engine for this rank: data only for owned views, factor mirrors for the others, every kernel
+    on the given HIP stream -- the torch stream the driver makes current around its broadcasts, so
+    that torch.distributed orders them against the kernels.  (The legacy NULL stream must not be
+    used: the library would fall back to a private non-blocking stream the broadcasts never see.)"""
+    from .engine import Engine
+
+    if not stream:
+        raise ValueError("a non-default HIP stream is required")
+    n_v = len(prob.init_f)
+    shapes = prob.extras["shapes"]
+    eng = Engine([s[0] for s in shapes], [s[1] for s in shapes], [prob.k] * n_v, owned=list(owned),
+                 device_id=device_index, stream=stream, **engine_opts)
+    for v in range(n_v):
+        if owned[v]:
+            eng.set_view(v, prob.data[v])
+        eng.set_factors(v, prob.init_f[v], prob.init_s[v], prob.init_g[v])
+    eng.set_restrictions(prob.phi, prob.xi, prob.psi)
+    row_sh, col_sh = naming.shared_names(prob.row_names), naming.shared_names(prob.col_names)
+    for v in range(n_v):
+        for w in range(n_v):
+            if w == v:
+                continue
+            iv, iw = naming.index_pairs(prob.row_names[v], prob.row_names[w], row_sh[v].get(w))
+            eng.set_shared_rows(v, w, iv, iw)
+            iv, iw = naming.index_pairs(prob.col_names[v], prob.col_names[w], col_sh[v].get(w))
+            eng.set_shared_cols(v, w, iv, iw)
+    return HipEngineAdapter(eng)
+
+
+def local_problem(n_views: int, shape, k: int, phi: float = 0.0, xi: float = 0.0, psi: float = 0.0,
+                  owned: Optional[Sequence[int]] = None) -> Problem:
+    """``synth.make_problem`` for equal-shaped views, generating the (large) data matrix only for the
+    views in ``owned``; the (small) initial factors of every view are generated everywhere, with
+    the same seeds as ``synth.make_problem`` (1000+v data, 2000+v factors)."""
+    n, m = shape
+    owned = list(range(n_views)) if owned is None else list(owned)
+    data, f0, s0, g0 = [], [], [], []
+    for v in range(n_views):
+        data.append(planted_view(n, m, k, 1000 + v) if v in owned else None)
+        f, s, g = random_init(n, m, k, 2000 + v)
+        f0.append(f); s0.append(s); g0.append(g)
+    off = 1.0 - np.eye(n_views)
+    prob = Problem(data, f0, s0, g0, phi * off, xi * off, psi * off, k, f"{n_views} views {n}x{m}")
+    rn, cn, rb, cb = [], [], 1, 1
+    for v in range(n_views):
+        if phi != 0.0:
+            rn.append([f"row_{t}" for t in range(1, n + 1)])
+        else:
+            rn.append([f"row_{t}" for t in range(rb, rb + n)]); rb += n
+        if psi != 0.0:
+            cn.append([f"col_{t}" for t in range(1, m + 1)])
+        else:
+            cn.append([f"col_{t}" for t in range(cb, cb + m)]); cb += m
+    prob.row_names, prob.col_names = rn, cn
+    prob.extras["shapes"] = [(n, m)] * n_views
+    return prob
+
+
+class ShardedSweep:
+    """Runs sweeps of a problem whose views are spread over the ranks of a process group."""
+
+    def __init__(self, prob: Problem, owner_of: Sequence[int], rank: int, world: int,
+                 device_index: int = 0, group=None, engine=None,
+                 engine_factory: Optional[Callable] = None, **engine_opts):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank, self.world = rank, world
+        self.n_views = len(prob.init_f)
+        self.owner_of = list(owner_of)
+        if len(self.owner_of) != self.n_views or any(o < 0 or o >= world for o in self.owner_of):
+            raise ValueError("owner_of must give a valid rank for every view")
+        self.owned = [o == rank for o in self.owner_of]
+        if "shapes" not in prob.extras:
+            prob.extras["shapes"] = [(f.shape[0], g.shape[0]) for f, g in zip(prob.init_f, prob.init_g)]
+        row_sh, col_sh = naming.shared_names(prob.row_names), naming.shared_names(prob.col_names)
+        self.plan = exchange_plan(self.n_views, self.owner_of, prob.phi, prob.xi, prob.psi, row_sh, col_sh)
+        self._tstream = None
+        if engine is not None:
+            self.engine = engine
+        elif engine_factory is not None:
+            self.engine = engine_factory(prob, self.owned)
+        else:
+            import torch
+            torch.cuda.set_device(device_index)
+            self._tstream = torch.cuda.Stream(device=device_index)
+            self.engine = make_hip_engine(prob, self.owned, device_index, self._tstream.cuda_stream, **engine_opts)
+        self.sweeps_done = 0
+        self._prepared = False
+
+    # ------------------------------------------------------------------
+    def _bcast(self, v: int, which: str):
+        t = self.engine.factor_tensor(v, which)
+        self.dist.broadcast(t, src=self.owner_of[v], group=self.group)
+
+    def run(self, n_sweeps: int):
+        """``n_sweeps`` more sweeps (fixed-iteration mode, R/main.r:83-108)."""
+        if n_sweeps <= 0:
+            return
+        if self._tstream is not None:
+            import torch
+            with torch.cuda.stream(self._tstream):      # broadcasts and kernels share this stream
+                self._run(n_sweeps)
+            return
+        self._run(n_sweeps)
+
+    def _run(self, n_sweeps: int):
+        if not self._prepared:
+            self.engine.reserve_sweeps(max(1024, n_sweeps))
+            self.engine.prepare()
+            self._prepared = True
+            self._reserved = max(1024, n_sweeps)
+        if self.sweeps_done + n_sweeps > self._reserved:
+            raise RuntimeError("reserve more sweeps before the first run() (errors are kept per sweep)")
+        for _ in range(n_sweeps):
+            t = self.sweeps_done
+            for v in range(self.n_views):
+                mine = self.owned[v]
+                if mine:
+                    self.engine.phase(v, PHASE_F, t)
+                if self.plan[v]["F"]:
+                    self._bcast(v, "F")
+                if mine:
+                    self.engine.phase(v, PHASE_G, t)
+                    self.engine.phase(v, PHASE_S, t)
+                if self.plan[v]["G"]:
+                    self._bcast(v, "G")
+                if self.plan[v]["S"]:
+                    self._bcast(v, "S")
+            self.sweeps_done += 1
+
+    # ------------------------------------------------------------------
+    def view_error_table(self) -> np.ndarray:
+        """[sweeps][views] relative errors, identical on every rank."""
+        mine = {v: np.asarray(self.engine.view_errors(v, 0, self.sweeps_done)) for v in range(self.n_views) if self.owned[v]}
+        gathered: List[Optional[dict]] = [None] * self.world
+        self.dist.all_gather_object(gathered, mine, group=self.group)
+        table = np.zeros((self.sweeps_done, self.n_views))
+        for part in gathered:
+            for v, e in part.items():
+                table[:, v] = e
+        return table
+
+    def mean_errors(self) -> np.ndarray:
+        """All_Error: mean over views per sweep (R/main.r:77-78,104-107)."""
+        return self.view_error_table().mean(axis=1)
+
+    def gather_results(self, dst: int = 0):
+        """normalisation_check + binary clusters of every view, collected on rank ``dst``."""
+        mine = {v: self.engine.finalise(v) for v in range(self.n_views) if self.owned[v]}
+        gathered: List[Optional[dict]] = [None] * self.world
+        self.dist.all_gather_object(gathered, mine, group=self.group)
+        if self.rank != dst:
+            return None
+        out: Dict[int, tuple] = {}
+        for part in gathered:
+            out.update(part)
+        keys = ("output_f", "output_s", "output_g", "row_clusters", "col_clusters")
+        return {k: [out[v][i] for v in range(self.n_views)] for i, k in enumerate(keys)}
+
+    def close(self):
+        self.engine.close()

@@ -1,0 +1,138 @@
+"""Worker process of the multi-rank tests (launched by tests/test_sharded_*.py, one per rank).
+
+mode "cpu": the ShardedSweep driver over gloo with a stand-in engine that evaluates each phase
+with the oracle's update rules on CPU tensors -- this exercises the product's exchange schedule
+(ordered broadcasts, running-list semantics, result gathering) without a GPU.
+mode "gpu": the same driver with the real HIP engine (both ranks may share one GPU), gloo backend.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+class OracleEngine:
+    """Stand-in engine (TEST ONLY): same interface as resnmtf_amd.sharded.HipEngineAdapter, phases
+    evaluated by oracle/resnmtf_oracle.py on CPU tensors.  Mirrors are plain tensors that the
+    driver's broadcasts overwrite in place."""
+
+    def __init__(self, prob, owned):
+        import torch
+        from oracle import resnmtf_oracle as O
+        self.O, self.torch = O, torch
+        self.prob, self.owned = prob, list(owned)
+        self.n_v = len(prob.init_f)
+        self.F = [torch.tensor(np.ascontiguousarray(f), dtype=torch.float64) for f in prob.init_f]
+        self.S = [torch.tensor(np.ascontiguousarray(s), dtype=torch.float64) for s in prob.init_s]
+        self.G = [torch.tensor(np.ascontiguousarray(g), dtype=torch.float64) for g in prob.init_g]
+        self.lam = [f.sum(0) for f in prob.init_f]
+        self.mu = [g.sum(0) for g in prob.init_g]
+        self.row_idx = O.reorder_data(prob.row_names)
+        self.col_idx = O.reorder_data(prob.col_names)
+        self.norms = [None if d is None else np.linalg.norm(d, "fro") ** 2 for d in prob.data]
+        self.errs = {v: [] for v in range(self.n_v) if self.owned[v]}
+
+    def reserve_sweeps(self, n): pass
+    def prepare(self): pass
+    def synchronize(self): pass
+    def close(self): pass
+
+    def _lists(self):
+        return [t.numpy() for t in self.F], [t.numpy() for t in self.S], [t.numpy() for t in self.G]
+
+    def phase(self, v, ph, sweep):
+        from resnmtf_amd._lib import PHASE_F, PHASE_G, PHASE_S
+        O, p = self.O, self.prob
+        fl, sl, gl = self._lists()
+        x = p.data[v]
+        if ph == PHASE_F:
+            new = O.update_f(x, fl, sl[v], gl[v], self.lam[v], p.phi, v, self.row_idx[v], p.row_names[v], p.row_names)
+            self.F[v].copy_(self.torch.from_numpy(new))
+        elif ph == PHASE_G:
+            newg = O.update_g(x, fl[v], sl[v], gl, self.mu[v], p.psi, v, self.col_idx[v], p.col_names[v], p.col_names)
+            self.G[v].copy_(self.torch.from_numpy(newg))
+            fl, sl, gl = self._lists()
+            news = O.update_s(x, fl[v], sl, gl[v], p.xi, v)
+            self.S[v].copy_(self.torch.from_numpy(news))
+            self.lam[v] = O.update_lm(self.lam[v], fl[v])
+            self.mu[v] = O.update_lm(self.mu[v], gl[v])
+            x_hat = (fl[v] @ news) @ gl[v].T
+            self.errs[v].append(np.linalg.norm(x - x_hat, "fro") ** 2 / self.norms[v])
+        elif ph == PHASE_S:
+            pass
+
+    def factor_tensor(self, v, which):
+        return {"F": self.F, "G": self.G, "S": self.S}[which][v].view(-1)
+
+    def view_errors(self, v, first, count):
+        return np.array(self.errs[v][first:first + count])
+
+    def finalise(self, v):
+        O = self.O
+        f, g, s = O.normalisation_check([self.F[v].numpy()], [self.G[v].numpy()], [self.S[v].numpy()])
+        rc, cc = O.binary_clusters(f, g, s)
+        return f[0], s[0], g[0], rc[0], cc[0]
+
+
+def build_problem():
+    """3 views, phi + psi + xi coupled, rows/columns partially shared at different positions."""
+    from resnmtf_amd.synth import Problem, planted_view, random_init
+    rng = np.random.default_rng(77)
+    shapes = [(96, 72), (80, 72), (96, 64)]
+    k = 5
+    data = [planted_view(n, m, k, 500 + v) for v, (n, m) in enumerate(shapes)]
+    inits = [random_init(n, m, k, 600 + v) for v, (n, m) in enumerate(shapes)]
+    rown = [[f"r{i}" for i in range(96)], [f"r{i}" for i in rng.permutation(np.arange(10, 90))],
+            [f"r{i}" for i in rng.permutation(96)]]
+    coln = [[f"c{i}" for i in range(72)], [f"c{i}" for i in rng.permutation(72)], [f"q{i}" for i in range(64)]]
+    up = np.triu(np.ones((3, 3)), 1)
+    sym = lambda a: a + a.T
+    prob = Problem(data, [i[0] for i in inits], [i[1] for i in inits], [i[2] for i in inits],
+                   sym(1.5 * up), sym(0.4 * up), sym(1.0 * up), k, row_names=rown, col_names=coln)
+    prob.extras["shapes"] = shapes
+    return prob
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rank", type=int, required=True)
+    ap.add_argument("--world", type=int, required=True)
+    ap.add_argument("--port", type=int, required=True)
+    ap.add_argument("--mode", choices=["cpu", "gpu"], required=True)
+    ap.add_argument("--sweeps", type=int, default=12)
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(a.port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from resnmtf_amd import sharded
+    dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
+    prob = build_problem()
+    owner_of = [v % a.world for v in range(3)]
+    if a.mode == "cpu":
+        drv = sharded.ShardedSweep(prob, owner_of, a.rank, a.world, engine_factory=lambda p, owned: OracleEngine(p, owned))
+    else:
+        drv = sharded.ShardedSweep(prob, owner_of, a.rank, a.world, device_index=0)
+    drv.run(a.sweeps // 2)
+    drv.run(a.sweeps - a.sweeps // 2)          # two calls: state carries over
+    errs = drv.mean_errors()
+    res = drv.gather_results(0)
+    drv.close()
+    if a.rank == 0:
+        out = {"all_error": errs}
+        for key, lst in res.items():
+            for v, arr in enumerate(lst):
+                out[f"{key}{v}"] = arr
+        np.savez(a.out, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

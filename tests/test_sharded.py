@@ -1,0 +1,95 @@
+"""Multi-rank path: world_size 2 over gloo.
+
+* CPU (not gpu): the product's ShardedSweep driver with a stand-in engine whose phases are the
+  oracle's update rules.  Checks that the ordered-broadcast schedule reproduces the reference's
+  Gauss-Seidel sweep EXACTLY (same arithmetic, so agreement to rounding of nothing: bitwise up to
+  the error formula) against the single-process oracle, plus the exchange-plan logic.
+* GPU (gpu): the same driver with the real HIP engine, two ranks sharing the one GPU of the box.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, rel_fro
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(mode, tmp_path, world=2, sweeps=12, timeout=600):
+    port = free_port()
+    out = str(tmp_path / f"sharded_{mode}.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "--rank", str(r),
+                               "--world", str(world), "--port", str(port), "--mode", mode, "--sweeps", str(sweeps),
+                               "--out", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    return np.load(out)
+
+
+def oracle_reference(sweeps=12):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_worker
+    from oracle import resnmtf_oracle as O
+    prob = dist_worker.build_problem()
+    return O.res_nmtf_inner(prob.data, prob.init_f, prob.init_s, prob.init_g, prob.phi, prob.xi, prob.psi,
+                            row_names=prob.row_names, col_names=prob.col_names, n_iters=sweeps)
+
+
+def test_exchange_plan():
+    from resnmtf_amd import naming
+    from resnmtf_amd.sharded import exchange_plan
+    names = [["a", "b", "c"], ["c", "a", "z"], ["q", "r", "s"]]
+    sh = naming.shared_names(names)
+    phi = np.array([[0, 2.0, 2.0], [2.0, 0, 0], [2.0, 0, 0]])
+    z = np.zeros((3, 3))
+    # views 0,1 on different ranks and sharing rows -> F of both travels; view 2 shares nothing (NA)
+    plan = exchange_plan(3, [0, 1, 0], phi, z, z, sh, sh)
+    assert plan[0]["F"] and plan[1]["F"] and not plan[2]["F"]
+    assert not any(p["G"] or p["S"] for p in plan)
+    # everything on one rank -> nothing travels
+    plan = exchange_plan(3, [0, 0, 0], phi, phi, phi, sh, sh)
+    assert not any(any(p.values()) for p in plan)
+    # xi couples S regardless of names
+    plan = exchange_plan(3, [0, 1, 1], z, phi, z, sh, sh)
+    assert plan[0]["S"] and plan[1]["S"] and plan[2]["S"]
+
+
+def test_sharded_schedule_matches_oracle_gloo_cpu(tmp_path):
+    got = launch("cpu", tmp_path)
+    ref = oracle_reference()
+    np.testing.assert_allclose(got["all_error"], ref["All_Error"], rtol=1e-12, atol=1e-14)
+    for v in range(3):
+        assert rel_fro(got[f"output_f{v}"], ref["output_f"][v]) < 1e-13
+        assert rel_fro(got[f"output_g{v}"], ref["output_g"][v]) < 1e-13
+        assert rel_fro(got[f"output_s{v}"], ref["output_s"][v]) < 1e-13
+        assert np.array_equal(got[f"row_clusters{v}"], ref["row_clusters"][v])
+        assert np.array_equal(got[f"col_clusters{v}"], ref["col_clusters"][v])
+
+
+@pytest.mark.gpu
+def test_sharded_hip_two_ranks_one_gpu(tmp_path):
+    got = launch("gpu", tmp_path)
+    ref = oracle_reference()
+    np.testing.assert_allclose(got["all_error"], ref["All_Error"], atol=2e-5, rtol=1e-4)
+    for v in range(3):
+        assert rel_fro(got[f"output_f{v}"], ref["output_f"][v]) < 2e-5
+        assert rel_fro(got[f"output_g{v}"], ref["output_g"][v]) < 2e-5
+        assert rel_fro(got[f"output_s{v}"], ref["output_s"][v]) < 1e-4

@@ -36,16 +36,23 @@ e.synchronize()
 nblk = 4096
 buf = torch.zeros((nblk, 16), dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
-e.phase(0, _lib.PHASE_F, 3); e.synchronize()
-assert lib.resnmtf_debug_set_stamp_buffer(C.c_void_p(buf.data_ptr())) == 0
-e.phase(0, _lib.PHASE_G, 3); e.synchronize()     # Xt.F pass + kk_f, G update, X.G pass + kk_s (the last stamps win)
+which = sys.argv[1] if len(sys.argv) > 1 else "F"
+if which == "F":
+    assert lib.resnmtf_debug_set_stamp_buffer(C.c_void_p(buf.data_ptr())) == 0
+    e.phase(0, _lib.PHASE_F, 3); e.synchronize()
+else:
+    e.phase(0, _lib.PHASE_F, 3); e.synchronize()
+    assert lib.resnmtf_debug_set_stamp_buffer(C.c_void_p(buf.data_ptr())) == 0
+    e.phase(0, _lib.PHASE_G, 3); e.synchronize()
 lib.resnmtf_debug_set_stamp_buffer(None)
 t = buf.cpu().numpy().astype(np.int64)
-row = t[0]
-names = {0: "kk_s entry", 1: "regs requested", 2: "colsum done", 3: "gram+cross summed", 4: "denominator mm",
-         5: "S', traces done", 6: "coefficients stored"}
-t0 = row[0]
-for idx in range(7):
-    if row[idx] > 0:
-        print(f"{names[idx]:30s} {(row[idx] - t0) / 100.0:8.2f} us")
+t = t[t[:, 0] > 0]
+print(f"{which} update: {len(t)} blocks stamped")
+t0 = t[:, 0].min()
+names = {0: "entry", 1: "operands landed (1st barrier)", 2: "rows computed + stored", 3: "2nd barrier", 4: "partials stored"}
+print(f"{'stage':34s} {'min':>8s} {'median':>8s} {'max':>8s}   (us since first block entry)")
+for idx in range(5):
+    col = t[:, idx]; col = col[col > 0]
+    rel = (col - t0) / 100.0
+    print(f"{names[idx]:34s} {rel.min():8.2f} {np.median(rel):8.2f} {rel.max():8.2f}")
 e.close()
