@@ -93,8 +93,8 @@ def run_single(args) -> dict:
     assert len(errs) == args.steps and np.isfinite(errs).all()
     eng.close()
 
-    # roofline leg: the same K sweeps, eager, every streaming-pass launch bracketed by HIP events
-    # on the library's stream (the dominant kernel is atb_pass_kernel: X.G and Xt.F passes)
+    # roofline leg: the same K sweeps, eager, every streaming-pass launch timed by HIP events attached
+    # to the dispatch on the library's stream (dominant kernels: the X.G and Xt.F streaming passes)
     eng2, _ = make_engine(time_kernels=True)
     if args.warmup > 0:
         eng2.run(min(args.warmup, 20))
@@ -106,7 +106,7 @@ def run_single(args) -> dict:
     pass_ms = (t["xg_ms_total"] + t["xtf_ms_total"]) / max(launches, 1)
     bytes_per_launch = (t["xg_bytes"] * t["xg_launches"] + t["xtf_bytes"] * t["xtf_launches"]) / max(launches, 1)
     achieved = bytes_per_launch / (pass_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "atb_pass_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+    roofline = {"bound": "hbm", "kernel": "pass_kkf_kernel/pass_kks_kernel (streaming pass body)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "avg_launch_us": round(pass_ms * 1e3, 3), "launches": int(launches),
                 "algorithmic_bytes_per_launch": bytes_per_launch,

@@ -12,6 +12,7 @@
 // A run starts with a prologue per view: Gram of the current G, then an X.G pass whose
 // workgroup 0 runs kk_s in mode 0 (F coefficients only).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -203,10 +204,14 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
   const int nw = xg ? v.nw_xg : v.nw_xtf;
   const dim3 grid(1 + a.ntiles * nsplit), block(64 * nw);
   const size_t smem = std::min<size_t>(pass_smem_bytes(v.KP, nw) + (size_t)h->opt.pass_lds_pad_kb * 1024, kMaxLds);
+  // timed mode: the start/stop events are attached to the dispatch itself (hipExtLaunchKernelGGL), so
+  // the elapsed time is the kernel's own begin->end, the same quantity rocprofv3 --kernel-trace reports
   const bool timed = h->opt.time_kernels && h->ev_used + 2 <= h->ev.size();
-  if (timed) (void)hipEventRecord(h->ev[h->ev_used], h->stream);
-#define LAUNCH_PASS(NTV, NWV, UV)                                                                          \
-  if (xg) hipLaunchKernelGGL((pass_kks_kernel<NTV, NWV, UV>), grid, block, smem, h->stream, a, ks);         \
+  hipEvent_t ev0 = timed ? h->ev[h->ev_used] : nullptr, ev1 = timed ? h->ev[h->ev_used + 1] : nullptr;
+#define LAUNCH_PASS(NTV, NWV, UV)                                                                                          \
+  if (timed && xg) hipExtLaunchKernelGGL((pass_kks_kernel<NTV, NWV, UV>), grid, block, smem, h->stream, ev0, ev1, 0, a, ks);  \
+  else if (timed) hipExtLaunchKernelGGL((pass_kkf_kernel<NTV, NWV, UV>), grid, block, smem, h->stream, ev0, ev1, 0, a, kf);   \
+  else if (xg) hipLaunchKernelGGL((pass_kks_kernel<NTV, NWV, UV>), grid, block, smem, h->stream, a, ks);                    \
   else hipLaunchKernelGGL((pass_kkf_kernel<NTV, NWV, UV>), grid, block, smem, h->stream, a, kf)
   switch (v.NT * 100 + nw) {
     case 101: LAUNCH_PASS(1, 1, 8); break;
@@ -230,7 +235,6 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
   }
 #undef LAUNCH_PASS
   if (timed) {
-    (void)hipEventRecord(h->ev[h->ev_used + 1], h->stream);
     h->ev_kind[h->ev_used / 2] = xg ? 0 : 1;
     h->ev_used += 2;
   }
