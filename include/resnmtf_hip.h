@@ -64,13 +64,16 @@ typedef struct resnmtf_options {
   int target_workgroups;  /* waves per streaming pass (sizes splits x waves-per-workgroup); 0 = default 4096 */
   int time_kernels;       /* 1: bracket every streaming-pass launch with HIP events (eager mode) */
   /* tuning overrides of the streaming-pass geometry (0 = automatic), see DESIGN.md section 5 */
-  int pass_waves;         /* waves per workgroup: 1, 2, 4, 8 or 16 */
+  int pass_waves;         /* waves per workgroup: 4, 8 or 16 (0 = auto) */
   int pass_splits_xg;     /* row splits of the X.G pass */
   int pass_splits_xtf;    /* row splits of the Xt.F pass */
   int pass_lds_pad_kb;    /* extra dynamic LDS per workgroup (caps workgroups per CU) */
   int update_blocks;      /* workgroups per factor-update launch (default 256) */
   int no_pitch_pad;       /* 1: do not pad row pitches that are multiples of 4 KiB (A/B testing) */
-  int reserved[2];
+  int kk_mode;            /* where the k x k products come from: 0 auto, 1 = A (fp64 partials of the update
+                             kernels, job in workgroup 0 of the pass launch), 2 = B (MFMA aux tiles, job in
+                             the last-arriving aux workgroup); DESIGN.md section 4 */
+  int reserved[1];
 } resnmtf_options;
 
 typedef struct resnmtf_pass_timing {

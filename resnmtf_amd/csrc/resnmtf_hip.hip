@@ -2,15 +2,15 @@
 // hipGraph capture and the C-ABI declared in include/resnmtf_hip.h.
 //
 // Schedule of one sweep (R/update_steps.r:272-319) for owned views v = 0..V-1, in order, ONE stream:
-//   F_v          factor_update<F>   update_f, reads U_v = X_v G_v; emits partial F'^T F', colSums(F')
-//   pass Xt.F    T_v = X_v^T F_v'   + workgroup 0: kk_f (F'^T F', G coefficients)
-//   G_v          factor_update<G>   update_g, reads T_v; emits partial G'^T G', T^T G', colSums(G')
-//   pass X.G'    U_v = X_v G_v'     + workgroup 0: kk_s (update_s, update_lm, error, next F coefficients)
-// Every k x k chain depends only on the factor that was just updated, so it runs as ONE extra
-// workgroup of the streaming-pass launch that follows that update and is hidden behind it.
-// Cross-view coupling (phi/psi: running F/G; xi: running S) is ordered by the stream.
-// A run starts with a prologue per view: Gram of the current G, then an X.G pass whose
-// workgroup 0 runs kk_s in mode 0 (F coefficients only).
+//   F_v          factor_update<F>   update_f, reads U_v = X_v G_v and the F coefficients
+//   pass Xt.F    main workgroups: T_v = X_v^T F_v'   | aux workgroups: F'^T F', colSums(F'); last arriver: kk_f
+//   G_v          factor_update<G>   update_g, reads T_v and the G coefficients
+//   pass X.G'    main workgroups: U_v = X_v G_v'     | aux workgroups: G'^T G', T^T G', colSums(G'); last arriver: kk_s
+// Every k x k chain (S rule, lambda/mu, error, coefficient matrices) depends only on the factor that
+// was just updated; it runs once, in the last-arriving aux workgroup of the pass launch that follows
+// that update, while the main workgroups stream X.  Cross-view coupling (phi/psi: running F/G;
+// xi: running S) is ordered by the stream.  A run starts with one X.G launch per view whose kk_s
+// runs in mode 0 (F coefficients from the current S and G).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -45,16 +45,19 @@ struct ViewState {
   float *X32 = nullptr, *Xt32 = nullptr;
   double* xnorm2 = nullptr;
   double *F = nullptr, *G = nullptr, *S = nullptr, *lambda = nullptr, *mu = nullptr;
-  float *F32 = nullptr, *G32 = nullptr;
-  int nsplit_xg = 1, rps_xg = 64, nw_xg = 4;
-  int nsplit_xtf = 1, rps_xtf = 64, nw_xtf = 4;
-  float *Pxg = nullptr, *Pxtf = nullptr;
+  float *F32 = nullptr, *G32 = nullptr, *T32 = nullptr;
+  int nsplit_xg = 1, rps_xg = 64, nw_xg = 4, nsaux_xg = 1, rpsaux_xg = 64;
+  int nsplit_xtf = 1, rps_xtf = 64, nw_xtf = 4, nsaux_xtf = 1, rpsaux_xtf = 64;
+  float *Pxg = nullptr, *Pxtf = nullptr, *Paux_xg = nullptr, *Paux_xtf = nullptr;
+  int *cnt_xg = nullptr, *cnt_xtf = nullptr;
   int rpbF = 16, nblkF = 1, rpbG = 16, nblkG = 1;
+  int kk_mode = 0;                   // 0 = A: Gram partials from the update kernels, k x k job = workgroup 0
+                                     // 1 = B: Gram/cross/colsum on MFMA aux tiles, k x k job = last-arriving aux workgroup
   double *partF = nullptr, *partG = nullptr;
   double *FtF = nullptr, *FtFS = nullptr, *cF = nullptr;
   double *Ma_F = nullptr, *Md_F = nullptr, *Ma_G = nullptr, *Md_G = nullptr;
   std::vector<SharedMap> row_map, col_map;   // indexed by the other view
-  UpdateArgs argF{}, argG{}, argGram{};
+  UpdateArgs argF{}, argG{};
   KKFArgs argKF{};
   KKSArgs argKS{};
   PassArgs passXG{}, passXtF{};
@@ -79,6 +82,7 @@ struct resnmtf_handle {
   hipGraphExec_t graph_multi = nullptr, graph_one = nullptr;
   int graph_multi_sweeps = 0;
   double graph_tol = -2.0;
+  int n_cu = 256;                     // compute units of the device (multiProcessorCount)
   // pass timing (eager mode)
   std::vector<hipEvent_t> ev;         // pairs
   std::vector<int> ev_kind;           // 0 = xg, 1 = xtf per pair
@@ -112,8 +116,8 @@ hipError_t dev_alloc_zero(T** p, size_t count) {
 }
 
 void free_view(ViewState& v) {
-  void* ptrs[] = {v.X32, v.Xt32, v.xnorm2, v.F, v.G, v.S, v.lambda, v.mu, v.F32, v.G32, v.Pxg, v.Pxtf,
-                  v.partF, v.partG, v.FtF, v.FtFS, v.cF, v.Ma_F, v.Md_F, v.Ma_G, v.Md_G};
+  void* ptrs[] = {v.X32, v.Xt32, v.xnorm2, v.F, v.G, v.S, v.lambda, v.mu, v.F32, v.G32, v.T32, v.Pxg, v.Pxtf,
+                  v.Paux_xg, v.Paux_xtf, v.cnt_xg, v.cnt_xtf, v.partF, v.partG, v.FtF, v.FtFS, v.cF, v.Ma_F, v.Md_F, v.Ma_G, v.Md_G};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& mp : v.row_map)
@@ -143,7 +147,7 @@ size_t update_smem_bytes(int KP) {
   const int RG = UPDATE_THREADS / KP;
   return sizeof(double) * ((size_t)2 * KP * KP + 3 * (size_t)RG * KP + 2 * UPDATE_THREADS);
 }
-size_t kk_smem_bytes(int KP, int NW) { return sizeof(double) * ((size_t)4 * KP * KP + 2 * 64 * (size_t)NW); }
+size_t kk_smem_bytes(int KP, int NW) { return sizeof(double) * ((size_t)4 * KP * KP + 3 * 64 * (size_t)NW); }
 size_t pass_smem_bytes(int KP, int NW) {
   return std::max(sizeof(float) * (size_t)std::max(NW / 2, 1) * 64 * KP, kk_smem_bytes(KP, NW));
 }
@@ -151,11 +155,15 @@ constexpr int kMaxLds = 160 * 1024;
 
 template <int NT, int NW, int UNROLL>
 hipError_t set_pass_attr() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kkf_kernel<NT, NW, UNROLL>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kks_kernel<NT, NW, UNROLL>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+  const void* fns[4] = {reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, false>),
+                        reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, false>),
+                        reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, true>),
+                        reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, true>)};
+  for (const void* fn : fns) {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 template <int KP>
@@ -166,10 +174,13 @@ hipError_t set_smem_attrs() {
                                (int)(bytes))) != hipSuccess)                                                   \
   return e
   SET_ATTR((factor_update_kernel<KP, false, false, false>), update_smem_bytes(KP));
-  SET_ATTR((factor_update_kernel<KP, false, false, true>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, false, true, false>), update_smem_bytes(KP));
   SET_ATTR((factor_update_kernel<KP, true, false, false>), update_smem_bytes(KP));
-  SET_ATTR((factor_update_kernel<KP, true, false, true>), update_smem_bytes(KP));
   SET_ATTR((factor_update_kernel<KP, true, true, false>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, false, false, true>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, false, true, true>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, true, false, true>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, true, true, true>), update_smem_bytes(KP));
 #undef SET_ATTR
   return hipSuccess;
 }
@@ -179,19 +190,18 @@ hipError_t set_all_attrs() {
 #define TRY_ATTR(x) if ((e = (x)) != hipSuccess) return e
   TRY_ATTR(set_smem_attrs<16>()); TRY_ATTR(set_smem_attrs<32>());
   TRY_ATTR(set_smem_attrs<48>()); TRY_ATTR(set_smem_attrs<64>());
-  TRY_ATTR((set_pass_attr<1, 1, 8>())); TRY_ATTR((set_pass_attr<1, 2, 8>()));
   TRY_ATTR((set_pass_attr<1, 4, 8>())); TRY_ATTR((set_pass_attr<1, 8, 8>())); TRY_ATTR((set_pass_attr<1, 16, 8>()));
-  TRY_ATTR((set_pass_attr<2, 1, 4>())); TRY_ATTR((set_pass_attr<2, 2, 4>()));
   TRY_ATTR((set_pass_attr<2, 4, 4>())); TRY_ATTR((set_pass_attr<2, 8, 4>())); TRY_ATTR((set_pass_attr<2, 16, 4>()));
-  TRY_ATTR((set_pass_attr<3, 1, 4>())); TRY_ATTR((set_pass_attr<3, 2, 4>()));
   TRY_ATTR((set_pass_attr<3, 4, 4>())); TRY_ATTR((set_pass_attr<3, 8, 4>()));
-  TRY_ATTR((set_pass_attr<4, 1, 4>())); TRY_ATTR((set_pass_attr<4, 2, 4>()));
   TRY_ATTR((set_pass_attr<4, 4, 4>())); TRY_ATTR((set_pass_attr<4, 8, 4>()));
 #undef TRY_ATTR
   return hipSuccess;
 }
 
 int max_pass_waves(int NT) { return NT <= 2 ? 16 : 8; }
+// workgroups of a pass launch one CU holds at once: the kernels' __launch_bounds__ (kernels.hip.inc,
+// pass_min_blocks) keeps the k <= 32 instantiations within 128 VGPRs
+int pass_blocks_per_cu(int NT, int nw) { return pass_min_blocks(NT, nw); }
 
 // xg = false: Xt.F pass + kk_f;  xg = true: X.G pass + kk_s (mode 0 = run prologue, 1 = full S update)
 void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, double tol, bool check_done) {
@@ -200,60 +210,61 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
   KKFArgs kf = v.argKF;
   KKSArgs ks = v.argKS;
   ks.mode = mode; ks.tol = tol;
-  const int nsplit = xg ? v.nsplit_xg : v.nsplit_xtf;
+  // mode A: the k x k job is workgroup 0 and reads the update kernel's fp64 partials
+  a.kk_block0 = (v.kk_mode == 0) ? 1 : 0;
+  if (!a.kk_block0) { kf.part = nullptr; ks.part = nullptr; }
   const int nw = xg ? v.nw_xg : v.nw_xtf;
-  const dim3 grid(1 + a.ntiles * nsplit), block(64 * nw);
+  const dim3 grid(a.kk_block0 ? 1 + a.ntiles * a.nsplit : a.naux * a.nsplit_aux + a.ntiles * a.nsplit), block(64 * nw);
   const size_t smem = std::min<size_t>(pass_smem_bytes(v.KP, nw) + (size_t)h->opt.pass_lds_pad_kb * 1024, kMaxLds);
   // timed mode: the start/stop events are attached to the dispatch itself (hipExtLaunchKernelGGL), so
   // the elapsed time is the kernel's own begin->end, the same quantity rocprofv3 --kernel-trace reports
   const bool timed = h->opt.time_kernels && h->ev_used + 2 <= h->ev.size();
   hipEvent_t ev0 = timed ? h->ev[h->ev_used] : nullptr, ev1 = timed ? h->ev[h->ev_used + 1] : nullptr;
-#define LAUNCH_PASS(NTV, NWV, UV)                                                                                          \
-  if (timed && xg) hipExtLaunchKernelGGL((pass_kks_kernel<NTV, NWV, UV>), grid, block, smem, h->stream, ev0, ev1, 0, a, ks);  \
-  else if (timed) hipExtLaunchKernelGGL((pass_kkf_kernel<NTV, NWV, UV>), grid, block, smem, h->stream, ev0, ev1, 0, a, kf);   \
-  else if (xg) hipLaunchKernelGGL((pass_kks_kernel<NTV, NWV, UV>), grid, block, smem, h->stream, a, ks);                    \
-  else hipLaunchKernelGGL((pass_kkf_kernel<NTV, NWV, UV>), grid, block, smem, h->stream, a, kf)
+#define LAUNCH_PASS_M(NTV, NWV, UV, XG, MA)                                                                              \
+  if (timed) hipExtLaunchKernelGGL((pass_kernel<NTV, NWV, UV, XG, MA>), grid, block, smem, h->stream, ev0, ev1, 0, a, kf, ks); \
+  else hipLaunchKernelGGL((pass_kernel<NTV, NWV, UV, XG, MA>), grid, block, smem, h->stream, a, kf, ks)
+#define LAUNCH_PASS(NTV, NWV, UV)                                   \
+  if (xg && a.kk_block0) { LAUNCH_PASS_M(NTV, NWV, UV, true, true); }      \
+  else if (xg) { LAUNCH_PASS_M(NTV, NWV, UV, true, false); }               \
+  else if (a.kk_block0) { LAUNCH_PASS_M(NTV, NWV, UV, false, true); }      \
+  else { LAUNCH_PASS_M(NTV, NWV, UV, false, false); }
   switch (v.NT * 100 + nw) {
-    case 101: LAUNCH_PASS(1, 1, 8); break;
-    case 102: LAUNCH_PASS(1, 2, 8); break;
     case 104: LAUNCH_PASS(1, 4, 8); break;
     case 108: LAUNCH_PASS(1, 8, 8); break;
     case 116: LAUNCH_PASS(1, 16, 8); break;
-    case 201: LAUNCH_PASS(2, 1, 4); break;
-    case 202: LAUNCH_PASS(2, 2, 4); break;
     case 204: LAUNCH_PASS(2, 4, 4); break;
     case 208: LAUNCH_PASS(2, 8, 4); break;
     case 216: LAUNCH_PASS(2, 16, 4); break;
-    case 301: LAUNCH_PASS(3, 1, 4); break;
-    case 302: LAUNCH_PASS(3, 2, 4); break;
     case 304: LAUNCH_PASS(3, 4, 4); break;
     case 308: LAUNCH_PASS(3, 8, 4); break;
-    case 401: LAUNCH_PASS(4, 1, 4); break;
-    case 402: LAUNCH_PASS(4, 2, 4); break;
     case 404: LAUNCH_PASS(4, 4, 4); break;
     default: LAUNCH_PASS(4, 8, 4); break;
   }
 #undef LAUNCH_PASS
+#undef LAUNCH_PASS_M
   if (timed) {
     h->ev_kind[h->ev_used / 2] = xg ? 0 : 1;
     h->ev_used += 2;
   }
 }
 
-// kind: 0 = F update, 1 = G update, 2 = Gram of the current G only (run prologue)
+// kind: 0 = F update, 1 = G update, 2 = mode A run prologue: partials of the current G, nothing updated
 void launch_update(resnmtf_handle* h, const ViewState& v, int kind, bool check_done) {
-  UpdateArgs a = kind == 0 ? v.argF : (kind == 1 ? v.argG : v.argGram);
+  UpdateArgs a = kind == 0 ? v.argF : v.argG;
   a.check_done = check_done ? 1 : 0;
+  a.gram_only = kind == 2 ? 1 : 0;
+  if (kind == 2) { a.restricted = 0; a.n_couple = 0; }
   const int nblk = kind == 0 ? v.nblkF : v.nblkG;
   const size_t smem = update_smem_bytes(v.KP);
-#define LAUNCH_UPD_K(KPV, G_, GO_, C_) \
-  hipLaunchKernelGGL((factor_update_kernel<KPV, G_, GO_, C_>), dim3(nblk), dim3(UPDATE_THREADS), smem, h->stream, a)
-#define LAUNCH_UPD(KPV)                                                              \
-  if (kind == 2) LAUNCH_UPD_K(KPV, true, true, false);                               \
-  else if (kind == 0 && a.restricted) LAUNCH_UPD_K(KPV, false, false, true);         \
-  else if (kind == 0) LAUNCH_UPD_K(KPV, false, false, false);                        \
-  else if (a.restricted) LAUNCH_UPD_K(KPV, true, false, true);                       \
-  else LAUNCH_UPD_K(KPV, true, false, false)
+  const bool emit = v.kk_mode == 0;
+#define LAUNCH_UPD_K(KPV, G_, C_)                                                                                      \
+  if (emit) hipLaunchKernelGGL((factor_update_kernel<KPV, G_, C_, true>), dim3(nblk), dim3(UPDATE_THREADS), smem, h->stream, a); \
+  else hipLaunchKernelGGL((factor_update_kernel<KPV, G_, C_, false>), dim3(nblk), dim3(UPDATE_THREADS), smem, h->stream, a)
+#define LAUNCH_UPD(KPV)                                                      \
+  if (kind == 0 && a.restricted) { LAUNCH_UPD_K(KPV, false, true); }         \
+  else if (kind == 0) { LAUNCH_UPD_K(KPV, false, false); }                   \
+  else if (a.restricted) { LAUNCH_UPD_K(KPV, true, true); }                  \
+  else { LAUNCH_UPD_K(KPV, true, false); }
   switch (v.NT) {
     case 1: LAUNCH_UPD(16); break;
     case 2: LAUNCH_UPD(32); break;
@@ -271,9 +282,10 @@ void enqueue_phase_g(resnmtf_handle* h, const ViewState& v, double tol, bool che
   launch_update(h, v, 1, checked);
   launch_pass(h, v, true, 1, tol, checked);
 }
-// run prologue of one view: Gram of the current G, then X.G pass + F coefficients (kk_s mode 0)
+// run prologue of one view: X.G launch whose kk_s runs in mode 0 (F coefficients from the current S, G);
+// mode A first emits the fp64 partials of the current G so that a resumed run is bitwise identical
 void enqueue_prologue(resnmtf_handle* h, const ViewState& v) {
-  launch_update(h, v, 2, false);
+  if (v.kk_mode == 0) launch_update(h, v, 2, false);
   launch_pass(h, v, true, 0, -1.0, false);
 }
 
@@ -318,22 +330,41 @@ int flush_timing(resnmtf_handle* h) {
   return RESNMTF_OK;
 }
 
-// sizes a streaming pass.  Measured on MI355X (tools/sweep_pass.py, tools/micro/pass_variants.hip):
-// 8 waves per workgroup, 16-24 steps of 4 rows per wave (a multiple of the unroll depth of 8) and as
-// few row splits as that allows; the splits are capped at 16, the depth of the consumer's prefetch.
-void size_pass(int ntiles, int rows_pad, int target_waves, int max_nw, int force_nw, int force_ns,
+// sizes a streaming pass.  Measured on MI355X (tools/sweep_pass.py, tools/stamps.py, tools/micro/):
+// 8 waves per workgroup.  `slots` = workgroups the device holds at once (CUs x resident workgroups
+// per CU, minus the k x k / aux workgroups of the launch).
+//   * one-round geometry: if the whole pass fits the slots with splits of at most 2048 rows, use
+//     floor(slots / ntiles) equal splits -- every workgroup is resident from t = 0, none waits for a
+//     slot and no CU is left with half the work of its neighbour (the quantisation that cost the
+//     628-workgroup / 255-slot X.G launch of c2 a third of its time);
+//   * otherwise 16-step workgroups (512 rows) that the dispatcher streams through the slots.
+// Splits are capped at 16, the depth of the consumer's prefetch.
+void size_pass(int ntiles, int rows_pad, int slots, int max_nw, int force_nw, int force_ns,
                int* nsplit, int* rps, int* nw) {
-  (void)ntiles; (void)target_waves;
   int w = std::min(8, max_nw);
-  if (force_nw == 1 || force_nw == 2 || force_nw == 4 || force_nw == 8 || force_nw == 16) w = std::min(force_nw, max_nw);
+  if (force_nw == 4 || force_nw == 8 || force_nw == 16) w = std::min(force_nw, max_nw);
   const int quantum = 4 * w * 8;                       // rows of one unrolled trip of a workgroup
   int r = 2 * quantum;                                 // 16 steps per wave
   if (ceil_div(rows_pad, r) > 16) r = round_up(ceil_div(rows_pad, 16), quantum);
+  const int ns_one = std::min(16, slots / std::max(ntiles, 1));
+  if (ns_one >= 1) {
+    const int r_one = round_up(ceil_div(rows_pad, ns_one), 64);
+    if (r_one <= 2048 && r_one >= quantum) r = r_one;
+  }
   if (force_ns > 0) r = round_up(ceil_div(rows_pad, force_ns), 64);
   r = std::min(r, round_up(rows_pad, 64));
   *rps = r;
   *nsplit = ceil_div(rows_pad, r);
   *nw = w;
+}
+// aux workgroups: one unrolled trip each (so they finish early), at most 64 splits per aux tile
+void size_aux(int rows_pad, int nw, int* nsplit, int* rps) {
+  const int quantum = 4 * nw * 8;
+  int r = quantum;
+  if (ceil_div(rows_pad, r) > 64) r = round_up(ceil_div(rows_pad, 64), quantum);
+  r = std::min(r, round_up(rows_pad, 64));
+  *rps = r;
+  *nsplit = ceil_div(rows_pad, r);
 }
 
 int sync_both(resnmtf_handle* h) {
@@ -406,13 +437,16 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
   hipError_t e = hipSetDevice(o.device_id);
   if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return RESNMTF_ERR_HIP; }
   hipDeviceProp_t prop;
+  int n_cu = 256;
   if (hipGetDeviceProperties(&prop, o.device_id) == hipSuccess) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
       g_create_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
       return RESNMTF_ERR_NO_DEVICE;
     }
+    if (prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
   }
   auto* h = new resnmtf_handle();
+  h->n_cu = n_cu;
   h->V = n_views;
   h->opt = o;
   if (h->opt.check_every < 1) h->opt.check_every = 8;
@@ -463,26 +497,50 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     if ((e = dev_alloc_zero(&vs.Xt32, (size_t)vs.m_pad * vs.ldxt)) != hipSuccess) return bail(e, "hipMalloc Xt32");
     if ((e = dev_alloc_zero(&vs.F32, (size_t)vs.n_pad * 64)) != hipSuccess) return bail(e, "hipMalloc F32");
     if ((e = dev_alloc_zero(&vs.G32, (size_t)vs.m_pad * 64)) != hipSuccess) return bail(e, "hipMalloc G32");
+    if ((e = dev_alloc_zero(&vs.T32, (size_t)vs.m_pad * 64)) != hipSuccess) return bail(e, "hipMalloc T32");
+    if ((e = dev_alloc_zero(&vs.cnt_xg, 4)) != hipSuccess) return bail(e, "hipMalloc cnt");
+    if ((e = dev_alloc_zero(&vs.cnt_xtf, 4)) != hipSuccess) return bail(e, "hipMalloc cnt");
     for (double** pp : {&vs.FtF, &vs.FtFS, &vs.Ma_F, &vs.Md_F, &vs.Ma_G, &vs.Md_G})
       if ((e = dev_alloc_zero(pp, kk)) != hipSuccess) return bail(e, "hipMalloc kxk");
     if ((e = dev_alloc_zero(&vs.cF, (size_t)vs.k)) != hipSuccess) return bail(e, "hipMalloc cF");
-    // target_workgroups is kept as the tuning knob's name; it counts WAVES of a streaming pass
-    const int target = o.target_workgroups > 0 ? o.target_workgroups : 4096;
-    size_pass(vs.n_pad / 64, vs.m_pad, target, max_pass_waves(vs.NT), o.pass_waves, o.pass_splits_xg,
+    // k x k mode (kernels.hip.inc, pass_kernel).  A (k <= 16): the update kernels emit fp64 partial
+    // Grams (1-4 KB per workgroup), the job is workgroup 0 of the next pass launch and runs beside the
+    // whole pass.  B (k > 16, where those partials would be 8-32 KB per workgroup): MFMA aux tiles in
+    // the pass launch, tiny slab volume at any k, the job starts once the aux workgroups are done and
+    // hides behind the (long) pass.  Measured on c2 ... 40000 x 2000 / 10000 x 8000 (tools/tune_c2.py):
+    // A wins at k = 16 for every size tried; B wins at k = 32 / 64 (tools/bench_configs.py).
+    const size_t xbytes = (size_t)vs.n * vs.m * sizeof(float);
+    vs.kk_mode = (vs.KP == 16) ? 0 : 1;
+    if (o.kk_mode == 1) vs.kk_mode = 0;
+    if (o.kk_mode == 2) vs.kk_mode = 1;
+    // workgroup slots of a pass launch: target_workgroups overrides CUs x resident workgroups per CU
+    const int nw_guess = (o.pass_waves == 4 || o.pass_waves == 8 || o.pass_waves == 16)
+                             ? std::min(o.pass_waves, max_pass_waves(vs.NT)) : 8;
+    size_aux(vs.m_pad, nw_guess, &vs.nsaux_xg, &vs.rpsaux_xg);
+    size_aux(vs.n_pad, nw_guess, &vs.nsaux_xtf, &vs.rpsaux_xtf);
+    const int slots_all = o.target_workgroups > 0 ? o.target_workgroups : h->n_cu * pass_blocks_per_cu(vs.NT, nw_guess);
+    const int slots_xg = slots_all - (vs.kk_mode == 0 ? 1 : 3 * vs.nsaux_xg);
+    const int slots_xtf = slots_all - (vs.kk_mode == 0 ? 1 : 2 * vs.nsaux_xtf);
+    size_pass(vs.n_pad / 64, vs.m_pad, slots_xg, max_pass_waves(vs.NT), o.pass_waves, o.pass_splits_xg,
               &vs.nsplit_xg, &vs.rps_xg, &vs.nw_xg);
-    size_pass(vs.m_pad / 64, vs.n_pad, target, max_pass_waves(vs.NT), o.pass_waves, o.pass_splits_xtf,
+    size_pass(vs.m_pad / 64, vs.n_pad, slots_xtf, max_pass_waves(vs.NT), o.pass_waves, o.pass_splits_xtf,
               &vs.nsplit_xtf, &vs.rps_xtf, &vs.nw_xtf);
     if ((e = dev_alloc_zero(&vs.Pxg, (size_t)vs.nsplit_xg * vs.n_pad * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Pxg");
     if ((e = dev_alloc_zero(&vs.Pxtf, (size_t)vs.nsplit_xtf * vs.m_pad * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Pxtf");
+    if ((e = dev_alloc_zero(&vs.Paux_xg, (size_t)3 * vs.nsaux_xg * 64 * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Paux");
+    if ((e = dev_alloc_zero(&vs.Paux_xtf, (size_t)2 * vs.nsaux_xtf * 64 * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Paux");
     const int RG = UPDATE_THREADS / vs.KP;
-    // one row group per update workgroup up to 256 workgroups: a single memory round trip per
-    // workgroup, and few enough partials that the k x k jobs sum them in a handful of load batches
-    const int nblk_target = o.update_blocks > 0 ? o.update_blocks : 256;
+    // update workgroups: mode A ~160 (few partials for the k x k job, two prefetched row groups each
+    // at c2 -- tools/tune_c2.py); mode B one row group per workgroup up to 1024 workgroups (a single
+    // memory round trip each)
+    const int nblk_target = o.update_blocks > 0 ? o.update_blocks : (vs.kk_mode == 0 ? (xbytes <= ((size_t)256 << 20) ? 160 : 512) : 1024);
     vs.rpbF = round_up(std::max(RG, ceil_div(vs.n, nblk_target)), RG); vs.nblkF = ceil_div(vs.n, vs.rpbF);
     vs.rpbG = round_up(std::max(RG, ceil_div(vs.m, nblk_target)), RG); vs.nblkG = ceil_div(vs.m, vs.rpbG);
-    const size_t kkp = (size_t)vs.KP * vs.KP;
-    if ((e = dev_alloc_zero(&vs.partF, (size_t)vs.nblkF * (kkp + vs.KP))) != hipSuccess) return bail(e, "hipMalloc partF");
-    if ((e = dev_alloc_zero(&vs.partG, (size_t)vs.nblkG * (2 * kkp + vs.KP))) != hipSuccess) return bail(e, "hipMalloc partG");
+    if (vs.kk_mode == 0) {
+      const size_t kkp = (size_t)vs.KP * vs.KP;
+      if ((e = dev_alloc_zero(&vs.partF, (size_t)vs.nblkF * (kkp + vs.KP))) != hipSuccess) return bail(e, "hipMalloc partF");
+      if ((e = dev_alloc_zero(&vs.partG, (size_t)vs.nblkG * (2 * kkp + vs.KP))) != hipSuccess) return bail(e, "hipMalloc partG");
+    }
   }
   if ((e = set_all_attrs()) != hipSuccess) return bail(e, "hipFuncSetAttribute");
   if (o.time_kernels) {
@@ -569,6 +627,9 @@ int resnmtf_set_factors(resnmtf_handle* h, int v, const double* F, const double*
     HIP_TRY(h, hipMemcpyAsync(vs.mu, muv.data(), muv.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(vs.F32, 0, (size_t)vs.n_pad * 64 * sizeof(float), h->stream));
     HIP_TRY(h, hipMemsetAsync(vs.G32, 0, (size_t)vs.m_pad * 64 * sizeof(float), h->stream));
+    HIP_TRY(h, hipMemsetAsync(vs.T32, 0, (size_t)vs.m_pad * 64 * sizeof(float), h->stream));
+    HIP_TRY(h, hipMemsetAsync(vs.cnt_xg, 0, 4 * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(vs.cnt_xtf, 0, 4 * sizeof(int), h->stream));
     hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(vs.n * vs.k, 256)), dim3(256), 0, h->stream, vs.F, vs.n,
                        vs.k, vs.F32);
     hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(vs.m * vs.k, 256)), dim3(256), 0, h->stream, vs.G, vs.m,
@@ -648,17 +709,23 @@ static int build_args(resnmtf_handle* h) {
     PassArgs& xg = vs.passXG;
     xg = PassArgs{};
     xg.A = vs.Xt32; xg.lda = vs.ldxt; xg.ntiles = vs.n_pad / 64; xg.B = vs.G32; xg.P = vs.Pxg;
-    xg.cols_pad = vs.n_pad; xg.rows_pad = vs.m_pad; xg.rows_per_split = vs.rps_xg; xg.ctl = h->ctl;
+    xg.cols_pad = vs.n_pad; xg.rows_pad = vs.m_pad; xg.rows_per_split = vs.rps_xg; xg.nsplit = vs.nsplit_xg;
+    xg.aux[0] = vs.G32; xg.aux[1] = vs.T32; xg.aux[2] = nullptr; xg.naux = 3;     // G^T G, T^T G, colSums(G)
+    xg.Paux = vs.Paux_xg; xg.rows_per_split_aux = vs.rpsaux_xg; xg.nsplit_aux = vs.nsaux_xg; xg.aux_cnt = vs.cnt_xg;
+    xg.ctl = h->ctl;
     PassArgs& xt = vs.passXtF;
     xt = PassArgs{};
     xt.A = vs.X32; xt.lda = vs.ldx; xt.ntiles = vs.m_pad / 64; xt.B = vs.F32; xt.P = vs.Pxtf;
-    xt.cols_pad = vs.m_pad; xt.rows_pad = vs.n_pad; xt.rows_per_split = vs.rps_xtf; xt.ctl = h->ctl;
+    xt.cols_pad = vs.m_pad; xt.rows_pad = vs.n_pad; xt.rows_per_split = vs.rps_xtf; xt.nsplit = vs.nsplit_xtf;
+    xt.aux[0] = vs.F32; xt.aux[1] = nullptr; xt.naux = 2;                          // F^T F, colSums(F)
+    xt.Paux = vs.Paux_xtf; xt.rows_per_split_aux = vs.rpsaux_xtf; xt.nsplit_aux = vs.nsaux_xtf; xt.aux_cnt = vs.cnt_xtf;
+    xt.ctl = h->ctl;
     // --- F update (R/update_steps.r:141-165)
     UpdateArgs& f = vs.argF;
     f = UpdateArgs{};
     f.len = vs.n; f.k = vs.k; f.W = vs.F; f.W32 = vs.F32;
     f.P = vs.Pxg; f.nsplit = vs.nsplit_xg; f.cols_pad = vs.n_pad;
-    f.Ma = vs.Ma_F; f.Md = vs.Md_F; f.lm = vs.lambda; f.part = vs.partF;
+    f.Ma = vs.Ma_F; f.Md = vs.Md_F; f.lm = vs.lambda; f.T32 = nullptr; f.part = vs.partF;
     f.rows_per_block = vs.rpbF; f.ctl = h->ctl;
     {
       double sigma = 0.0;
@@ -681,7 +748,7 @@ static int build_args(resnmtf_handle* h) {
     g = UpdateArgs{};
     g.len = vs.m; g.k = vs.k; g.W = vs.G; g.W32 = vs.G32;
     g.P = vs.Pxtf; g.nsplit = vs.nsplit_xtf; g.cols_pad = vs.m_pad;
-    g.Ma = vs.Ma_G; g.Md = vs.Md_G; g.lm = vs.mu; g.part = vs.partG;
+    g.Ma = vs.Ma_G; g.Md = vs.Md_G; g.lm = vs.mu; g.T32 = vs.T32; g.part = vs.partG;
     g.rows_per_block = vs.rpbG; g.ctl = h->ctl;
     {
       double sigma = 0.0;
@@ -699,13 +766,11 @@ static int build_args(resnmtf_handle* h) {
         c.W = h->views[i].G; c.map = mp.dev; c.weight = wgt; c.n_other = (double)h->views[i].m;
       }
     }
-    vs.argGram = g;            // same geometry; the GRAM_ONLY instantiation ignores the update inputs
-    vs.argGram.restricted = 0; vs.argGram.n_couple = 0;
     // --- k x k side kernels
     KKFArgs& kf = vs.argKF;
     kf = KKFArgs{};
-    kf.k = vs.k; kf.part = vs.partF; kf.nblk = vs.nblkF; kf.S = vs.S;
-    kf.FtF = vs.FtF; kf.FtFS = vs.FtFS; kf.Ma_G = vs.Ma_G; kf.Md_G = vs.Md_G; kf.cF = vs.cF; kf.ctl = h->ctl;
+    kf.k = vs.k; kf.S = vs.S; kf.part = vs.partF; kf.nblk = vs.nblkF;
+    kf.FtF = vs.FtF; kf.FtFS = vs.FtFS; kf.Ma_G = vs.Ma_G; kf.Md_G = vs.Md_G; kf.cF = vs.cF;
     KKSArgs& ks = vs.argKS;
     ks = KKSArgs{};
     ks.k = vs.k; ks.mode = 1; ks.part = vs.partG; ks.nblk = vs.nblkG;
