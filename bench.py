@@ -156,6 +156,8 @@ def run_sharded(args) -> dict:
     prob = sharded.local_problem(n_views, (n, m), k, phi=200.0, owned=[rank])
     drv = sharded.ShardedSweep(prob, owner_of=list(range(n_views)), rank=rank, world=world,
                                device_index=local_rank)
+    if os.environ.get("RESNMTF_FORCE_BCAST") == "1":      # rehearsal: issue the F broadcast even with one rank
+        drv.plan[0]["F"] = True
     drv.run(args.warmup)
     dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()

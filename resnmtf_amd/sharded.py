@@ -17,9 +17,20 @@ exchange is a sequence of ordered broadcasts, one per (view, factor) that some o
 Only the small factor blocks (n x k, m x k, k x k) travel; the streaming passes over X -- all
 of the HBM traffic -- touch own-view data only.  Uncoupled views need no exchange at all.
 
+Streams (GPU path): the engine's kernels run on a dedicated compute stream, the broadcasts on a
+second (exchange) stream, ordered against each other by HIP events only where the data demands it:
+
+    broadcast of F_v      waits for the latest PHASE_F enqueued on this rank  (root: F_v is complete;
+                          receiver: nobody still reads the old mirror of F_v)
+    broadcast of G_v/S_v  waits for the latest PHASE_G/PHASE_S enqueued on this rank  (same two reasons)
+    PHASE_F / PHASE_G     wait for the latest broadcast enqueued before them
+
+so a rank's two streaming passes (PHASE_G, all of the HBM traffic) overlap the other ranks' F
+updates and broadcasts of the same sweep; only the F chain itself -- which the reference's
+Gauss-Seidel order makes serial -- stays on the critical path.
+
 The engine is injected (``engine`` argument) so that the identical driver code runs in the CPU
-tests on a stand-in engine; in production it is ``resnmtf_amd.engine.Engine`` and every kernel
-and every broadcast is enqueued on torch's current HIP stream.
+tests on a stand-in engine (no streams); in production it is ``resnmtf_amd.engine.Engine``.
 """
 from __future__ import annotations
 
@@ -184,7 +195,10 @@ class ShardedSweep:
             prob.extras["shapes"] = [(f.shape[0], g.shape[0]) for f, g in zip(prob.init_f, prob.init_g)]
         row_sh, col_sh = naming.shared_names(prob.row_names), naming.shared_names(prob.col_names)
         self.plan = exchange_plan(self.n_views, self.owner_of, prob.phi, prob.xi, prob.psi, row_sh, col_sh)
-        self._tstream = None
+        self._tstream = None      # compute stream (GPU path only)
+        self._xstream = None      # exchange stream
+        self._ev_f = self._ev_g = self._ev_x = None
+        self._serial = bool(engine_opts.pop("serial_exchange", False))   # one-stream fallback (diagnostic)
         if engine is not None:
             self.engine = engine
         elif engine_factory is not None:
@@ -193,6 +207,7 @@ class ShardedSweep:
             import torch
             torch.cuda.set_device(device_index)
             self._tstream = torch.cuda.Stream(device=device_index)
+            self._xstream = self._tstream if self._serial else torch.cuda.Stream(device=device_index)
             self.engine = make_hip_engine(prob, self.owned, device_index, self._tstream.cuda_stream, **engine_opts)
         self.sweeps_done = 0
         self._prepared = False
@@ -200,7 +215,44 @@ class ShardedSweep:
     # ------------------------------------------------------------------
     def _bcast(self, v: int, which: str):
         t = self.engine.factor_tensor(v, which)
-        self.dist.broadcast(t, src=self.owner_of[v], group=self.group)
+        if self._tstream is None:                      # CPU stand-in engine: plain blocking broadcast
+            self.dist.broadcast(t, src=self.owner_of[v], group=self.group)
+            return
+        import torch
+        after = self._ev_f if which == "F" else self._ev_g
+        if after is not None and self._xstream is not self._tstream:
+            self._xstream.wait_event(after)
+        with torch.cuda.stream(self._xstream):         # torch.distributed orders the collective on the current stream
+            self.dist.broadcast(t, src=self.owner_of[v], group=self.group)
+        if self._xstream is not self._tstream:
+            self._ev_x = self._next_event()
+            self._ev_x.record(self._xstream)
+
+    def _next_event(self):
+        """Events are recycled round-robin: a wait captures the record that precedes it, so an event
+        may be re-recorded while earlier waits on it are still queued."""
+        import torch
+        if not hasattr(self, "_ev_pool"):
+            self._ev_pool = [torch.cuda.Event() for _ in range(64)]
+            self._ev_next = 0
+        ev = self._ev_pool[self._ev_next]
+        self._ev_next = (self._ev_next + 1) % len(self._ev_pool)
+        return ev
+
+    def _phase(self, v: int, phases, sweep: int, reads_mirrors: bool):
+        """Enqueue phases of an owned view on the compute stream, after the broadcasts they read."""
+        two = self._tstream is not None and self._xstream is not self._tstream
+        if two and reads_mirrors and self._ev_x is not None:
+            self._tstream.wait_event(self._ev_x)
+        for ph in phases:
+            self.engine.phase(v, ph, sweep)
+        if two:
+            ev = self._next_event()
+            ev.record(self._tstream)
+            if phases[0] == PHASE_F:
+                self._ev_f = ev
+            else:
+                self._ev_g = ev
 
     def run(self, n_sweeps: int):
         """``n_sweeps`` more sweeps (fixed-iteration mode, R/main.r:83-108)."""
@@ -208,7 +260,7 @@ class ShardedSweep:
             return
         if self._tstream is not None:
             import torch
-            with torch.cuda.stream(self._tstream):      # broadcasts and kernels share this stream
+            with torch.cuda.stream(self._tstream):
                 self._run(n_sweeps)
             return
         self._run(n_sweeps)
@@ -219,6 +271,7 @@ class ShardedSweep:
             self.engine.prepare()
             self._prepared = True
             self._reserved = max(1024, n_sweeps)
+            self._gs_exchanged = any(p["G"] or p["S"] for p in self.plan)
         if self.sweeps_done + n_sweeps > self._reserved:
             raise RuntimeError("reserve more sweeps before the first run() (errors are kept per sweep)")
         for _ in range(n_sweeps):
@@ -226,12 +279,11 @@ class ShardedSweep:
             for v in range(self.n_views):
                 mine = self.owned[v]
                 if mine:
-                    self.engine.phase(v, PHASE_F, t)
+                    self._phase(v, (PHASE_F,), t, True)                      # reads the mirrors of coupled F_w
                 if self.plan[v]["F"]:
                     self._bcast(v, "F")
                 if mine:
-                    self.engine.phase(v, PHASE_G, t)
-                    self.engine.phase(v, PHASE_S, t)
+                    self._phase(v, (PHASE_G, PHASE_S), t, self._gs_exchanged)  # reads G_w / S_w mirrors if exchanged
                 if self.plan[v]["G"]:
                     self._bcast(v, "G")
                 if self.plan[v]["S"]:
