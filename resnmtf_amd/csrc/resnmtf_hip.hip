@@ -631,9 +631,9 @@ int resnmtf_set_factors(resnmtf_handle* h, int v, const double* F, const double*
     HIP_TRY(h, hipMemsetAsync(vs.cnt_xg, 0, 4 * sizeof(int), h->stream));
     HIP_TRY(h, hipMemsetAsync(vs.cnt_xtf, 0, 4 * sizeof(int), h->stream));
     hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(vs.n * vs.k, 256)), dim3(256), 0, h->stream, vs.F, vs.n,
-                       vs.k, vs.F32);
+                       vs.k, vs.F32, vs.kk_mode == 0 ? vs.KP : 64);
     hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(vs.m * vs.k, 256)), dim3(256), 0, h->stream, vs.G, vs.m,
-                       vs.k, vs.G32);
+                       vs.k, vs.G32, vs.kk_mode == 0 ? vs.KP : 64);
     HIP_TRY(h, hipGetLastError());
   }
   HIP_TRY(h, hipStreamSynchronize(h->stream));   // host vectors go out of scope
@@ -708,14 +708,14 @@ static int build_args(resnmtf_handle* h) {
     // --- streaming passes
     PassArgs& xg = vs.passXG;
     xg = PassArgs{};
-    xg.A = vs.Xt32; xg.lda = vs.ldxt; xg.ntiles = vs.n_pad / 64; xg.B = vs.G32; xg.P = vs.Pxg;
+    xg.A = vs.Xt32; xg.lda = vs.ldxt; xg.ntiles = vs.n_pad / 64; xg.B = vs.G32; xg.ldb = vs.kk_mode == 0 ? vs.KP : 64; xg.P = vs.Pxg;
     xg.cols_pad = vs.n_pad; xg.rows_pad = vs.m_pad; xg.rows_per_split = vs.rps_xg; xg.nsplit = vs.nsplit_xg;
     xg.aux[0] = vs.G32; xg.aux[1] = vs.T32; xg.aux[2] = nullptr; xg.naux = 3;     // G^T G, T^T G, colSums(G)
     xg.Paux = vs.Paux_xg; xg.rows_per_split_aux = vs.rpsaux_xg; xg.nsplit_aux = vs.nsaux_xg; xg.aux_cnt = vs.cnt_xg;
     xg.ctl = h->ctl;
     PassArgs& xt = vs.passXtF;
     xt = PassArgs{};
-    xt.A = vs.X32; xt.lda = vs.ldx; xt.ntiles = vs.m_pad / 64; xt.B = vs.F32; xt.P = vs.Pxtf;
+    xt.A = vs.X32; xt.lda = vs.ldx; xt.ntiles = vs.m_pad / 64; xt.B = vs.F32; xt.ldb = vs.kk_mode == 0 ? vs.KP : 64; xt.P = vs.Pxtf;
     xt.cols_pad = vs.m_pad; xt.rows_pad = vs.n_pad; xt.rows_per_split = vs.rps_xtf; xt.nsplit = vs.nsplit_xtf;
     xt.aux[0] = vs.F32; xt.aux[1] = nullptr; xt.naux = 2;                          // F^T F, colSums(F)
     xt.Paux = vs.Paux_xtf; xt.rows_per_split_aux = vs.rpsaux_xtf; xt.nsplit_aux = vs.nsaux_xtf; xt.aux_cnt = vs.cnt_xtf;
@@ -723,7 +723,7 @@ static int build_args(resnmtf_handle* h) {
     // --- F update (R/update_steps.r:141-165)
     UpdateArgs& f = vs.argF;
     f = UpdateArgs{};
-    f.len = vs.n; f.k = vs.k; f.W = vs.F; f.W32 = vs.F32;
+    f.len = vs.n; f.k = vs.k; f.W = vs.F; f.W32 = vs.F32; f.ld32 = vs.kk_mode == 0 ? vs.KP : 64;
     f.P = vs.Pxg; f.nsplit = vs.nsplit_xg; f.cols_pad = vs.n_pad;
     f.Ma = vs.Ma_F; f.Md = vs.Md_F; f.lm = vs.lambda; f.T32 = nullptr; f.part = vs.partF;
     f.rows_per_block = vs.rpbF; f.ctl = h->ctl;
@@ -746,7 +746,7 @@ static int build_args(resnmtf_handle* h) {
     // --- G update (R/update_steps.r:180-207); branch on the WHOLE psi matrix (:190)
     UpdateArgs& g = vs.argG;
     g = UpdateArgs{};
-    g.len = vs.m; g.k = vs.k; g.W = vs.G; g.W32 = vs.G32;
+    g.len = vs.m; g.k = vs.k; g.W = vs.G; g.W32 = vs.G32; g.ld32 = vs.kk_mode == 0 ? vs.KP : 64;
     g.P = vs.Pxtf; g.nsplit = vs.nsplit_xtf; g.cols_pad = vs.m_pad;
     g.Ma = vs.Ma_G; g.Md = vs.Md_G; g.lm = vs.mu; g.T32 = vs.T32; g.part = vs.partG;
     g.rows_per_block = vs.rpbG; g.ctl = h->ctl;

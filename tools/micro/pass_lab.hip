@@ -16,7 +16,7 @@ __global__ __launch_bounds__(64 * NW, 2 * NW / 4) void lab_pass(const float* A, 
   extern __shared__ __attribute__((aligned(16))) float red_lab[];
   const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
   const int r_begin = split * rps;
-  pass_body<1, NW, 8>(A + (size_t)tile * 64, lda, B, r_begin, min(r_begin + rps, rows_pad), red_lab,
+  pass_body<1, NW, 8>(A + (size_t)tile * 64, lda, B, 64, r_begin, min(r_begin + rps, rows_pad), red_lab,
                       P + ((size_t)split * cols_pad + (size_t)tile * 64) * 16);
 }
 

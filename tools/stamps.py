@@ -62,7 +62,8 @@ for name, base in (("Xt.F", 8), ("X.G", 0)):
         print("  aux ticket    ", st(us(aux[:, 2])))
     kk = t[t[:, 4] > 0]
     for row in kk:
-        print(f"  k x k job: entry {(row[0]-t0)/100:.2f}  acquire done {((row[3]-t0)/100 if row[3] else float('nan')):.2f}  done {(row[4]-t0)/100:.2f}")
+        extra = "  ".join(f"s{c}={(row[c]-t0)/100:.2f}" for c in (5, 6, 7) if row[c] > 0)
+        print(f"  k x k job: entry {(row[0]-t0)/100:.2f}  acquire done {((row[3]-t0)/100 if row[3] else float('nan')):.2f}  done {(row[4]-t0)/100:.2f}  {extra}")
     # concurrency profile: how many main workgroups are alive at each microsecond
     ent, end = us(main[:, 0]), us(main[:, 1])
     prof = [int(((ent <= x) & (end > x)).sum()) for x in np.arange(0, end.max() + 1, 1.0)]
