@@ -337,14 +337,22 @@ int flush_timing(resnmtf_handle* h) {
 //     floor(slots / ntiles) equal splits -- every workgroup is resident from t = 0, none waits for a
 //     slot and no CU is left with half the work of its neighbour (the quantisation that cost the
 //     628-workgroup / 255-slot X.G launch of c2 a third of its time);
-//   * otherwise 16-step workgroups (512 rows) that the dispatcher streams through the slots.
+//   * otherwise 16-step workgroups (512 rows; longer for k > 32) that the dispatcher streams through
+//     the slots.
 // Splits are capped at 16, the depth of the consumer's prefetch.
-void size_pass(int ntiles, int rows_pad, int slots, int max_nw, int force_nw, int force_ns,
+void size_pass(int NT, int ntiles, int rows_pad, int slots, int max_nw, int force_nw, int force_ns,
                int* nsplit, int* rps, int* nw) {
   int w = std::min(8, max_nw);
   if (force_nw == 4 || force_nw == 8 || force_nw == 16) w = std::min(force_nw, max_nw);
   const int quantum = 4 * w * 8;                       // rows of one unrolled trip of a workgroup
-  int r = 2 * quantum;                                 // 16 steps per wave
+  // streamed geometry: 16-step workgroups (512 rows); for k > 32 only about 8 workgroups per slot, i.e.
+  // longer splits -- there the per-workgroup epilogue (tree sum of 64 accumulator registers per lane +
+  // slab store) costs as much as several trips (c5 X.G pass: 744 -> 602 us; k <= 32 prefers short splits)
+  int r = 2 * quantum;
+  if (NT >= 3) {
+    const int ns_stream = std::max(1, std::min(16, ceil_div(8 * (slots + 1), std::max(ntiles, 1))));
+    r = std::max(r, round_up(ceil_div(rows_pad, ns_stream), 64));
+  }
   if (ceil_div(rows_pad, r) > 16) r = round_up(ceil_div(rows_pad, 16), quantum);
   const int ns_one = std::min(16, slots / std::max(ntiles, 1));
   if (ns_one >= 1) {
@@ -521,9 +529,9 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     const int slots_all = o.target_workgroups > 0 ? o.target_workgroups : h->n_cu * pass_blocks_per_cu(vs.NT, nw_guess);
     const int slots_xg = slots_all - (vs.kk_mode == 0 ? 1 : 3 * vs.nsaux_xg);
     const int slots_xtf = slots_all - (vs.kk_mode == 0 ? 1 : 2 * vs.nsaux_xtf);
-    size_pass(vs.n_pad / 64, vs.m_pad, slots_xg, max_pass_waves(vs.NT), o.pass_waves, o.pass_splits_xg,
+    size_pass(vs.NT, vs.n_pad / 64, vs.m_pad, slots_xg, max_pass_waves(vs.NT), o.pass_waves, o.pass_splits_xg,
               &vs.nsplit_xg, &vs.rps_xg, &vs.nw_xg);
-    size_pass(vs.m_pad / 64, vs.n_pad, slots_xtf, max_pass_waves(vs.NT), o.pass_waves, o.pass_splits_xtf,
+    size_pass(vs.NT, vs.m_pad / 64, vs.n_pad, slots_xtf, max_pass_waves(vs.NT), o.pass_waves, o.pass_splits_xtf,
               &vs.nsplit_xtf, &vs.rps_xtf, &vs.nw_xtf);
     if ((e = dev_alloc_zero(&vs.Pxg, (size_t)vs.nsplit_xg * vs.n_pad * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Pxg");
     if ((e = dev_alloc_zero(&vs.Pxtf, (size_t)vs.nsplit_xtf * vs.m_pad * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Pxtf");
@@ -631,9 +639,9 @@ int resnmtf_set_factors(resnmtf_handle* h, int v, const double* F, const double*
     HIP_TRY(h, hipMemsetAsync(vs.cnt_xg, 0, 4 * sizeof(int), h->stream));
     HIP_TRY(h, hipMemsetAsync(vs.cnt_xtf, 0, 4 * sizeof(int), h->stream));
     hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(vs.n * vs.k, 256)), dim3(256), 0, h->stream, vs.F, vs.n,
-                       vs.k, vs.F32, vs.kk_mode == 0 ? vs.KP : 64);
+                       vs.k, vs.F32, vs.kk_mode == 0 ? vs.KP : 64, vs.NT);
     hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(vs.m * vs.k, 256)), dim3(256), 0, h->stream, vs.G, vs.m,
-                       vs.k, vs.G32, vs.kk_mode == 0 ? vs.KP : 64);
+                       vs.k, vs.G32, vs.kk_mode == 0 ? vs.KP : 64, vs.NT);
     HIP_TRY(h, hipGetLastError());
   }
   HIP_TRY(h, hipStreamSynchronize(h->stream));   // host vectors go out of scope
