@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 METRIC = "multiplicative-update iters/sec (all views)"
 
 
-def cpu_baseline(prob, warm: int = 2, timed: int = 10) -> dict:
+def cpu_baseline(prob, warm: int = 3, timed: int = 20) -> dict:
     """The oracle (literal fp64 restatement: four passes over X per sweep, materialised
     residual -- the BLAS call sequence R would issue) on the host cores; NumPy/OpenBLAS."""
     from oracle import resnmtf_oracle as O
@@ -106,7 +106,7 @@ def run_single(args) -> dict:
     pass_ms = (t["xg_ms_total"] + t["xtf_ms_total"]) / max(launches, 1)
     bytes_per_launch = (t["xg_bytes"] * t["xg_launches"] + t["xtf_bytes"] * t["xtf_launches"]) / max(launches, 1)
     achieved = bytes_per_launch / (pass_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "pass_kkf_kernel/pass_kks_kernel (streaming pass body)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+    roofline = {"bound": "hbm", "kernel": "pass_kernel<NT,NW,UNROLL,IS_XG,MODE_A> (X.G and Xt.F streaming passes, same pass_body)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "avg_launch_us": round(pass_ms * 1e3, 3), "launches": int(launches),
                 "algorithmic_bytes_per_launch": bytes_per_launch,

@@ -3,14 +3,15 @@
 //
 // Schedule of one sweep (R/update_steps.r:272-319) for owned views v = 0..V-1, in order, ONE stream:
 //   F_v          factor_update<F>   update_f, reads U_v = X_v G_v and the F coefficients
-//   pass Xt.F    main workgroups: T_v = X_v^T F_v'   | aux workgroups: F'^T F', colSums(F'); last arriver: kk_f
+//   pass Xt.F    main workgroups: T_v = X_v^T F_v'   | k x k job kk_f
 //   G_v          factor_update<G>   update_g, reads T_v and the G coefficients
-//   pass X.G'    main workgroups: U_v = X_v G_v'     | aux workgroups: G'^T G', T^T G', colSums(G'); last arriver: kk_s
+//   pass X.G'    main workgroups: U_v = X_v G_v'     | k x k job kk_s
 // Every k x k chain (S rule, lambda/mu, error, coefficient matrices) depends only on the factor that
-// was just updated; it runs once, in the last-arriving aux workgroup of the pass launch that follows
-// that update, while the main workgroups stream X.  Cross-view coupling (phi/psi: running F/G;
-// xi: running S) is ordered by the stream.  A run starts with one X.G launch per view whose kk_s
-// runs in mode 0 (F coefficients from the current S and G).
+// was just updated; it runs once inside the pass launch that follows that update, while the main
+// workgroups stream X: as workgroup 0 fed by the update kernel's fp64 partials (mode A, k <= 16) or
+// in the last-arriving MFMA aux workgroup (mode B) -- see resnmtf_kernels.hip.inc.  Cross-view
+// coupling (phi/psi: running F/G; xi: running S) is ordered by the stream.  A run starts with one
+// X.G launch per view whose kk_s runs in mode 0 (F coefficients from the current S and G).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 

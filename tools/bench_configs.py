@@ -39,7 +39,9 @@ for name in a.configs:
                     e.set_shared_cols(v, w, *naming.index_pairs(prob.col_names[v], prob.col_names[w], cs[v].get(w)))
         return e
     e = mk(); e.run(5)
-    t0 = time.perf_counter(); errs = e.run(a.sweeps); dt = time.perf_counter() - t0
+    dt = 1e9
+    for _ in range(3):                 # best of three (box-to-box and run-to-run noise is a few %)
+        t0 = time.perf_counter(); errs = e.run(a.sweeps); dt = min(dt, time.perf_counter() - t0)
     e.close()
     e = mk(time_kernels=True); e.run(3); e.pass_timings(reset=True); e.run(20); t = e.pass_timings(); e.close()
     xg = t["xg_ms_total"] / t["xg_launches"] * 1e3; xtf = t["xtf_ms_total"] / t["xtf_launches"] * 1e3
