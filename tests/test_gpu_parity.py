@@ -173,3 +173,62 @@ def test_full_size_c2_properties():
     assert abs(errs[-1] - lit_raw) < 1e-6, (errs[-1], lit_raw)
     assert np.array_equal(errs, a["All_Error"])
     assert np.isfinite(lit)
+
+
+def _engine_for(prob):
+    """Engine loaded with a (possibly multi-view, coupled) problem -- the C-ABI call sequence of api.py."""
+    from resnmtf_amd import naming
+    from resnmtf_amd.engine import Engine
+    shapes = [x.shape for x in prob.data]
+    n_v = len(shapes)
+    e = Engine([s[0] for s in shapes], [s[1] for s in shapes], [prob.k] * n_v)
+    for v in range(n_v):
+        e.set_view(v, prob.data[v])
+        e.set_factors(v, prob.init_f[v], prob.init_s[v], prob.init_g[v])
+    e.set_restrictions(prob.phi, prob.xi, prob.psi)
+    rs, cs = naming.shared_names(prob.row_names), naming.shared_names(prob.col_names)
+    for v in range(n_v):
+        for w in range(n_v):
+            if v != w:
+                e.set_shared_rows(v, w, *naming.index_pairs(prob.row_names[v], prob.row_names[w], rs[v].get(w)))
+                e.set_shared_cols(v, w, *naming.index_pairs(prob.col_names[v], prob.col_names[w], cs[v].get(w)))
+    return e
+
+
+@pytest.mark.parametrize("name", ["c3", "c4v1", "c4", "c5v1", "c5v2"])
+def test_full_size_single_sweep_parity(name):
+    """BASELINE shapes too large for a multi-sweep oracle run: ONE literal oracle sweep
+    (R/update_steps.r:272-319 + R/utils.r:157-166) from the device's own state after 10 sweeps must
+    reproduce the device's 11th sweep -- F, G, S, lambda, mu and the error -- at full size:
+    c3 = 2 phi-coupled views 10000 x {2000, 1500} k = 16; c4 = 4 views 20000 x 4000 k = 32 phi+psi
+    (c4v1: one of them, hand-off mode B); c5v1 / c5v2 = one / two views of c5 (50000 x 8000, k = 64,
+    phi+psi+xi -- all eight would need 26 GB of fp64 host data for no additional code path)."""
+    from oracle import resnmtf_oracle as O
+    if name in ("c3", "c4"):
+        prob = synth.config(name)
+    elif name == "c5v2":
+        prob = synth.make_problem([(50000, 8000)] * 2, 64, phi=200.0, psi=200.0, xi=200.0)
+    elif name == "c4v1":
+        prob = synth.make_problem([(20000, 4000)], 32)
+    else:
+        prob = synth.make_problem([(50000, 8000)], 64)
+    n_v = len(prob.data)
+    e = _engine_for(prob)
+    e.run(10)
+    st0 = [e.get_factors(v) for v in range(n_v)]          # (F, S, G, lambda, mu) raw
+    err11 = e.run(1)
+    st1 = [e.get_factors(v) for v in range(n_v)]
+    e.close()
+    rn, cn = prob.row_names, prob.col_names
+    ri, ci = O.reorder_data(rn), O.reorder_data(cn)
+    f1, s1, g1, lam1, mu1 = O.update_matrices(prob.data, [s[0] for s in st0], [s[1] for s in st0], [s[2] for s in st0],
+                                              [s[3] for s in st0], [s[4] for s in st0], prob.phi, prob.xi, prob.psi,
+                                              ri, ci, rn, cn)
+    norms = np.array([np.linalg.norm(d, "fro") ** 2 for d in prob.data])
+    err_ref = O.calculate_error(prob.data, f1, s1, g1, norms).mean()
+    for v in range(n_v):
+        assert rel_fro(st1[v][0], f1[v]) < TOL_FG, f"F view {v}"
+        assert rel_fro(st1[v][2], g1[v]) < TOL_FG, f"G view {v}"
+        assert rel_fro(st1[v][1], s1[v]) < TOL_S, f"S view {v}"
+        assert rel_fro(st1[v][3], lam1[v]) < TOL_FG and rel_fro(st1[v][4], mu1[v]) < TOL_FG
+    assert abs(err11[-1] - err_ref) < TOL_ERR, (err11[-1], err_ref)
