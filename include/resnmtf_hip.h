@@ -113,6 +113,16 @@ int resnmtf_destroy(resnmtf_handle* h);
 int resnmtf_set_view(resnmtf_handle* h, int v, const double* x);
 
 /*
+ * Upload a RAW data matrix and pre-process it on the device, fused into the upload pass:
+ * make_non_neg_inner (per COLUMN shift by |min(0, min(column))|, R/utils.r:20-27) followed by
+ * matrix_normalisation (divide by colSums, R/utils.r:86-88) -- what check_inputs does at
+ * R/utils.r:416,422 -- then data_norms as above.  *was_negative (may be NULL) is set to 1 when an
+ * entry was negative, the condition of the reference's warning (R/utils.r:23-25).  A zero column
+ * yields NaN, as in the reference.
+ */
+int resnmtf_set_view_raw(resnmtf_handle* h, int v, const double* x_raw, int* was_negative);
+
+/*
  * Initial factors of view v (owned or mirror): F n x k, S k x k, G m x k, column-major.
  * lambda / mu may be NULL: they are then colSums(F) / colSums(G), the reference's
  * explicit-init branch (R/update_steps.r:49-56).

@@ -577,7 +577,10 @@ int resnmtf_destroy(resnmtf_handle* h) {
   return RESNMTF_OK;
 }
 
-int resnmtf_set_view(resnmtf_handle* h, int v, const double* x) {
+namespace {
+// raw = false: x is already non-negative and column-normalised.  raw = true: make_non_neg_inner +
+// matrix_normalisation (R/utils.r:20-27, 86-88) run on the device, fused into the conversion.
+int upload_view(resnmtf_handle* h, int v, const double* x, bool raw, int* was_negative) {
   if (int rc = check_view(h, v)) return rc;
   if (!x) return h->fail(RESNMTF_ERR_INVALID, "x is NULL");
   ViewState& vs = h->views[v];
@@ -587,26 +590,43 @@ int resnmtf_set_view(resnmtf_handle* h, int v, const double* x) {
   const size_t count = (size_t)vs.n * vs.m;
   double* staging = nullptr;
   double* partial = nullptr;
+  double* colstat = nullptr;      // [2][m]: shift, colsum; then one int flag
   const dim3 grid(ceil_div(vs.n, 32), ceil_div(vs.m, 32));
   const int nparts = grid.x * grid.y;
   HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&staging), count * sizeof(double)));
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&partial), (size_t)nparts * sizeof(double));
-  if (e != hipSuccess) { (void)hipFree(staging); return h->fail_hip("hipMalloc partial", e); }
+  if (e == hipSuccess && raw) e = hipMalloc(reinterpret_cast<void**>(&colstat), ((size_t)2 * vs.m + 1) * sizeof(double));
+  if (e != hipSuccess) { (void)hipFree(staging); (void)hipFree(partial); return h->fail_hip("hipMalloc upload buffers", e); }
+  double* shift = raw ? colstat : nullptr;
+  double* colsum = raw ? colstat + vs.m : nullptr;
+  int* neg = raw ? reinterpret_cast<int*>(colstat + 2 * (size_t)vs.m) : nullptr;
+  int neg_host = 0;
   e = hipMemcpyAsync(staging, x, count * sizeof(double), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) e = hipMemsetAsync(vs.X32, 0, (size_t)vs.n_pad * vs.ldx * sizeof(float), h->stream);
   if (e == hipSuccess) e = hipMemsetAsync(vs.Xt32, 0, (size_t)vs.m_pad * vs.ldxt * sizeof(float), h->stream);
+  if (e == hipSuccess && raw) e = hipMemsetAsync(neg, 0, sizeof(double), h->stream);
   if (e == hipSuccess) {
+    if (raw) hipLaunchKernelGGL(column_stats_kernel, dim3(vs.m), dim3(256), 0, h->stream, staging, vs.n, vs.m, shift, colsum, neg);
     hipLaunchKernelGGL(convert_x_kernel, grid, dim3(256), 0, h->stream, staging, vs.n, vs.m, vs.X32, vs.ldx,
-                       vs.Xt32, vs.ldxt, partial);
+                       vs.Xt32, vs.ldxt, partial, shift, colsum);
     hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, h->stream, partial, nparts, vs.xnorm2);
     e = hipGetLastError();
   }
+  if (e == hipSuccess && raw) e = hipMemcpyAsync(&neg_host, neg, sizeof(int), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   (void)hipFree(staging);
   (void)hipFree(partial);
+  (void)hipFree(colstat);
   if (e != hipSuccess) return h->fail_hip("set_view", e);
+  if (was_negative) *was_negative = neg_host;
   vs.has_x = true;
   return RESNMTF_OK;
+}
+}  // namespace
+
+int resnmtf_set_view(resnmtf_handle* h, int v, const double* x) { return upload_view(h, v, x, false, nullptr); }
+int resnmtf_set_view_raw(resnmtf_handle* h, int v, const double* x_raw, int* was_negative) {
+  return upload_view(h, v, x_raw, true, was_negative);
 }
 
 int resnmtf_set_factors(resnmtf_handle* h, int v, const double* F, const double* S, const double* G,

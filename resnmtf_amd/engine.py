@@ -102,6 +102,16 @@ class Engine:
         x = _f64_colmajor(x, (self.n_rows[v], self.n_cols[v]))
         self._check(self._lib.resnmtf_set_view(self._h, v, _dp(x)))
 
+    def set_view_raw(self, v: int, x_raw) -> bool:
+        """Upload a raw view; the non-negativity shift and the column normalisation of
+        ``check_inputs`` (``R/utils.r:416,422``) run on the device.  Returns True when an entry was
+        negative (the reference warns, ``R/utils.r:23-25``)."""
+        import ctypes as C
+        x = _f64_colmajor(x_raw, (self.n_rows[v], self.n_cols[v]))
+        neg = C.c_int(0)
+        self._check(self._lib.resnmtf_set_view_raw(self._h, v, _dp(x), C.byref(neg)))
+        return bool(neg.value)
+
     def set_factors(self, v: int, f, s, g, lam=None, mu=None):
         k = self.k[v]
         f = _f64_colmajor(f, (self.n_rows[v], k))

@@ -232,3 +232,40 @@ def test_full_size_single_sweep_parity(name):
         assert rel_fro(st1[v][1], s1[v]) < TOL_S, f"S view {v}"
         assert rel_fro(st1[v][3], lam1[v]) < TOL_FG and rel_fro(st1[v][4], mu1[v]) < TOL_FG
     assert abs(err11[-1] - err_ref) < TOL_ERR, (err11[-1], err_ref)
+
+
+@pytest.mark.parametrize("shape,k", [((300, 170), 4), ((1000, 333), 16)])
+def test_raw_upload_preprocessing_matches_oracle(shape, k):
+    """resnmtf_set_view_raw: make_non_neg_inner + matrix_normalisation (R/utils.r:20-27, 86-88) on the
+    device vs the oracle's host pre-processing followed by the plain upload -- same factors after 30
+    sweeps (the two differ only in the summation order of colSums), negative-entry flag as the
+    reference's warning condition."""
+    from oracle import resnmtf_oracle as O
+    from resnmtf_amd.engine import Engine
+    rng = np.random.default_rng(7)
+    n, m = shape
+    raw = synth.planted_view(n, m, k, 11) * 50.0 + rng.normal(0.0, 0.5, size=(n, m))   # some columns go negative
+    raw[:, ::7] = np.abs(raw[:, ::7])                                                      # ... and some do not
+    assert (raw.min(axis=0) < 0).any() and (raw.min(axis=0) >= 0).any()
+    pre = O.matrix_normalisation(O.make_non_neg(raw))
+    f0, s0, g0 = synth.random_init(n, m, k, 5)
+    outs = []
+    for mode in ("raw", "host"):
+        e = Engine([n], [m], [k])
+        if mode == "raw":
+            assert e.set_view_raw(0, raw) is True
+        else:
+            e.set_view(0, pre)
+        e.set_restrictions(); e.set_factors(0, f0, s0, g0)
+        errs = e.run(30)
+        outs.append((e.finalise(0), errs))
+        e.close()
+    (fa, sa, ga, rca, cca), ea = outs[0]
+    (fb, sb, gb, rcb, ccb), eb = outs[1]
+    assert rel_fro(fa, fb) < 1e-6 and rel_fro(ga, gb) < 1e-6 and rel_fro(sa, sb) < 1e-5
+    np.testing.assert_allclose(ea, eb, atol=1e-7)
+    ref = run_oracle(synth.Problem([pre], [f0], [s0], [g0], np.zeros((1, 1)), np.zeros((1, 1)), np.zeros((1, 1)), k), n_iters=30)
+    assert rel_fro(fa, ref["output_f"][0]) < TOL_FG and rel_fro(ga, ref["output_g"][0]) < TOL_FG
+    e = Engine([n], [m], [k])
+    assert e.set_view_raw(0, np.abs(raw)) is False          # nothing negative: no warning condition
+    e.close()
