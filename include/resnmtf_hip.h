@@ -131,6 +131,21 @@ int resnmtf_set_factors(resnmtf_handle* h, int v, const double* F, const double*
                         const double* G, const double* lambda, const double* mu);
 
 /*
+ * Initial factors of an owned view from its data: init_mats_inner (R/update_steps.r:78-125) --
+ * F0 = |U[, 1:k]|, G0 = |V[, 1:k]| of the SVD of X, S0 = |diag(d)[1:k, 1:k]| + |N(0, sigma I)| noise,
+ * S0 columns scaled by colSums(F0) * colSums(G0), F0 and G0 column-L1-normalised, lambda / mu their
+ * column sums.  The reference calls a full svd(); here the k leading triplets come from a randomized
+ * subspace iteration (n_power >= 1 iterations, 0 = default 3; sketch width 16 ceil((k + 8) / 16) <= 64)
+ * whose big products are the streaming-pass kernels, and the noise from a std::mt19937_64 seeded with
+ * `seed` (R's RNG / MASS::mvrnorm are not reproducible outside R): statistically, not bitwise,
+ * equivalent; singular vectors of (near-)equal singular values are determined up to rotation in
+ * either implementation.  sigma = 0.05 is the reference's default.  singular_values (k, may be NULL)
+ * receives d[1:k].  Requires resnmtf_set_view / resnmtf_set_view_raw; replaces resnmtf_set_factors.
+ */
+int resnmtf_init_svd(resnmtf_handle* h, int v, unsigned long long seed, double sigma, int n_power,
+                     double* singular_values);
+
+/*
  * Restriction matrices, n_views x n_views column-major, ALREADY symmetrised with zero diagonal
  * (the output of init_rest_mats, R/update_steps.r:12-24).  NULL = all zero.
  */

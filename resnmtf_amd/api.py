@@ -48,13 +48,17 @@ def svd_init(data: Sequence[np.ndarray], k_vec: Sequence[int], seed: Optional[in
 
 
 def _load_engine(eng: Engine, data, init_f, init_s, init_g, lam, mu, phi, xi, psi,
-                 row_names, col_names, row_indices, column_indices):
+                 row_names, col_names, row_indices, column_indices, seed=None):
+    """``init_f is None``: the initial factors come from the device (``resnmtf_init_svd``)."""
     n_v = eng.n_views
     for v in range(n_v):
         if eng.owned[v]:
             eng.set_view(v, data[v])
-        eng.set_factors(v, init_f[v], init_s[v], init_g[v],
-                        None if lam is None else lam[v], None if mu is None else mu[v])
+        if init_f is None:
+            eng.init_svd(v, seed=(0 if seed is None else int(seed)) + v)                          # update_steps.r:78-125
+        else:
+            eng.set_factors(v, init_f[v], init_s[v], init_g[v],
+                            None if lam is None else lam[v], None if mu is None else mu[v])
     eng.set_restrictions(phi, xi, psi)
     for v in range(n_v):
         for w in range(n_v):
@@ -72,7 +76,8 @@ def res_nmtf_inner(data, row_indices, column_indices,
                    k_vec=None, phi=None, xi=None, psi=None,
                    n_iters=None, num_repeats=5, spurious=True, distance="euclidean",
                    no_clusts=False, *, row_names=None, col_names=None, device_id: int = 0,
-                   max_iters: int = 100000, seed: Optional[int] = None, engine_opts: Optional[dict] = None):
+                   max_iters: int = 100000, seed: Optional[int] = None, engine_opts: Optional[dict] = None,
+                   host_init: bool = False):
     """``res_nmtf_inner`` (``R/main.r:32-140``).
 
     ``data``: list of pre-processed (non-negative, column-normalised) matrices; ``row_indices[v][w]``
@@ -81,7 +86,9 @@ def res_nmtf_inner(data, row_indices, column_indices,
     ``res_nmtf_inner`` needs them non-NULL, ``R/update_steps.r:150``); ``n_iters=None`` runs to
     convergence.  Keyword-only extras: ``row_names``/``col_names`` (the reference reads them off
     the matrices' dimnames), ``max_iters`` (a guard the reference lacks), ``seed`` for the SVD
-    init noise.
+    init noise, ``host_init`` (without explicit initial factors: ``False`` = ``init_mats_inner`` on
+    the device, randomized top-k SVD on the pass kernels, milliseconds; ``True`` = NumPy's full SVD
+    on the host as the reference's ``svd()``, seconds to minutes -- statistically equivalent).
     """
     data = [np.asarray(d, dtype=np.float64) for d in _as_list(data)]
     n_v = len(data)
@@ -110,14 +117,17 @@ def res_nmtf_inner(data, row_indices, column_indices,
 
     lam = mu = None
     if init_f is None or init_g is None or init_s is None:                                        # update_steps.r:41
-        init_f, init_s, init_g, lam, mu = svd_init(data, k_vec, seed)
-    init_f, init_s, init_g = _as_list(init_f), _as_list(init_s), _as_list(init_g)
+        init_f = init_s = init_g = None
+        if host_init:
+            init_f, init_s, init_g, lam, mu = svd_init(data, k_vec, seed)
+    if init_f is not None:
+        init_f, init_s, init_g = _as_list(init_f), _as_list(init_s), _as_list(init_g)
 
     eng = Engine([d.shape[0] for d in data], [d.shape[1] for d in data], k_vec, device_id=device_id,
                  **(engine_opts or {}))
     try:
         _load_engine(eng, data, init_f, init_s, init_g, lam, mu, phi, xi, psi,
-                     row_names, col_names, row_indices, column_indices)
+                     row_names, col_names, row_indices, column_indices, seed=seed)
         total_err = eng.run(n_iters=n_iters, tol=1.0e-6, max_iters=max_iters)
         out_f, out_s, out_g, row_cl, col_cl, lams, mus = [], [], [], [], [], [], []
         for v in range(n_v):

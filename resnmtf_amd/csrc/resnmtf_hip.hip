@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -247,6 +248,25 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
     h->ev_kind[h->ev_used / 2] = xg ? 0 : 1;
     h->ev_used += 2;
   }
+}
+
+// a streaming pass without a k x k job (SVD initialisation): mode A kernel, workgroup 0 idles
+void launch_pass_plain(resnmtf_handle* h, PassArgs a, int NT, bool xg) {
+  a.kk_block0 = 1; a.no_kk = 1; a.check_done = 0;
+  const KKFArgs kf{};
+  const KKSArgs ks{};
+  const dim3 grid(1 + a.ntiles * a.nsplit), block(64 * 8);
+  const size_t smem = std::min<size_t>(pass_smem_bytes(16 * NT, 8), kMaxLds);
+#define LAUNCH_PLAIN(NTV, UV)                                                                                      \
+  if (xg) hipLaunchKernelGGL((pass_kernel<NTV, 8, UV, true, true>), grid, block, smem, h->stream, a, kf, ks);      \
+  else hipLaunchKernelGGL((pass_kernel<NTV, 8, UV, false, true>), grid, block, smem, h->stream, a, kf, ks)
+  switch (NT) {
+    case 1: LAUNCH_PLAIN(1, 8); break;
+    case 2: LAUNCH_PLAIN(2, 4); break;
+    case 3: LAUNCH_PLAIN(3, 4); break;
+    default: LAUNCH_PLAIN(4, 4); break;
+  }
+#undef LAUNCH_PLAIN
 }
 
 // kind: 0 = F update, 1 = G update, 2 = mode A run prologue: partials of the current G, nothing updated
@@ -668,6 +688,226 @@ int resnmtf_set_factors(resnmtf_handle* h, int v, const double* F, const double*
   HIP_TRY(h, hipStreamSynchronize(h->stream));   // host vectors go out of scope
   vs.has_factors = true;
   return RESNMTF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// resnmtf_init_svd -- init_mats_inner (R/update_steps.r:78-125) for one view, SURVEY 8(f1).
+// Randomized subspace iteration (L = 16 ceil((k + 8) / 16) <= 64 columns): the two big products per
+// iteration are the streaming-pass kernels; CholeskyQR2 orthonormalisation and the final L x L
+// symmetric eigenproblem are fp64, their L x L factorisations on the host.
+// ---------------------------------------------------------------------------------------------
+namespace {
+// C (L x L, row-major, symmetric positive definite) = R^T R, R upper triangular; returns false if not PD
+bool cholesky_upper(const std::vector<double>& C, int L, std::vector<double>& R) {
+  R.assign((size_t)L * L, 0.0);
+  for (int j = 0; j < L; ++j) {
+    double d = C[(size_t)j * L + j];
+    for (int t = 0; t < j; ++t) d -= R[(size_t)t * L + j] * R[(size_t)t * L + j];
+    if (!(d > 0.0)) return false;
+    const double rjj = std::sqrt(d);
+    R[(size_t)j * L + j] = rjj;
+    for (int c = j + 1; c < L; ++c) {
+      double v = C[(size_t)j * L + c];
+      for (int t = 0; t < j; ++t) v -= R[(size_t)t * L + j] * R[(size_t)t * L + c];
+      R[(size_t)j * L + c] = v / rjj;
+    }
+  }
+  return true;
+}
+void invert_upper(const std::vector<double>& R, int L, std::vector<double>& Ri) {
+  Ri.assign((size_t)L * L, 0.0);
+  for (int j = 0; j < L; ++j) {
+    Ri[(size_t)j * L + j] = 1.0 / R[(size_t)j * L + j];
+    for (int i = j - 1; i >= 0; --i) {
+      double v = 0.0;
+      for (int t = i + 1; t <= j; ++t) v += R[(size_t)i * L + t] * Ri[(size_t)t * L + j];
+      Ri[(size_t)i * L + j] = -v / R[(size_t)i * L + i];
+    }
+  }
+}
+// cyclic Jacobi for a symmetric L x L matrix: A -> eigenvalues (diagonal), V columns = eigenvectors
+void jacobi_eigen(std::vector<double>& A, int L, std::vector<double>& V) {
+  V.assign((size_t)L * L, 0.0);
+  for (int i = 0; i < L; ++i) V[(size_t)i * L + i] = 1.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int i = 0; i < L; ++i)
+      for (int j = 0; j < L; ++j) (i == j ? diag : off) += A[(size_t)i * L + j] * A[(size_t)i * L + j];
+    if (off <= 1e-30 * diag) break;
+    for (int p = 0; p < L - 1; ++p)
+      for (int q = p + 1; q < L; ++q) {
+        const double apq = A[(size_t)p * L + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[(size_t)q * L + q] - A[(size_t)p * L + p]) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int r = 0; r < L; ++r) {           // columns p, q
+          const double arp = A[(size_t)r * L + p], arq = A[(size_t)r * L + q];
+          A[(size_t)r * L + p] = c * arp - sn * arq;
+          A[(size_t)r * L + q] = sn * arp + c * arq;
+        }
+        for (int r = 0; r < L; ++r) {           // rows p, q
+          const double apr = A[(size_t)p * L + r], aqr = A[(size_t)q * L + r];
+          A[(size_t)p * L + r] = c * apr - sn * aqr;
+          A[(size_t)q * L + r] = sn * apr + c * aqr;
+        }
+        for (int r = 0; r < L; ++r) {
+          const double vrp = V[(size_t)r * L + p], vrq = V[(size_t)r * L + q];
+          V[(size_t)r * L + p] = c * vrp - sn * vrq;
+          V[(size_t)r * L + q] = sn * vrp + c * vrq;
+        }
+      }
+  }
+}
+
+struct InitScratch {
+  double *Yn = nullptr, *Yn2 = nullptr, *Zm = nullptr, *Zm2 = nullptr, *gpart = nullptr, *gram = nullptr, *M = nullptr;
+  float *Pn = nullptr, *Pm = nullptr;
+  bool own_pn = false, own_pm = false;
+  ~InitScratch() {
+    for (double* p : {Yn, Yn2, Zm, Zm2, gpart, gram, M}) if (p) (void)hipFree(p);
+    if (own_pn && Pn) (void)hipFree(Pn);
+    if (own_pm && Pm) (void)hipFree(Pm);
+  }
+};
+constexpr int kGramBlocks = 256;
+
+// gram = Y^T Y (L x L) on the host
+int ts_gram_host(resnmtf_handle* h, InitScratch& sc, const double* Y, int len, int L, std::vector<double>& C) {
+  const int rpb = round_up(ceil_div(len, kGramBlocks), 16), nblk = ceil_div(len, rpb);
+  hipLaunchKernelGGL(ts_gram_kernel, dim3(nblk), dim3(256), 0, h->stream, Y, len, L, rpb, sc.gpart);
+  hipLaunchKernelGGL(reduce_records_kernel, dim3(ceil_div(L * L, 256)), dim3(256), 0, h->stream, sc.gpart, nblk, L * L, sc.gram);
+  C.resize((size_t)L * L);
+  HIP_TRY(h, hipMemcpyAsync(C.data(), sc.gram, C.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return RESNMTF_OK;
+}
+int ts_apply(resnmtf_handle* h, InitScratch& sc, const double* Y, int len, int L, const std::vector<double>& M,
+             double* Q, float* W32, int nt) {
+  HIP_TRY(h, hipMemcpyAsync(sc.M, M.data(), M.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(ts_apply_kernel, dim3(ceil_div(len * L, 256)), dim3(256), 0, h->stream, Y, len, L, sc.M, Q, W32, 64, nt);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));       // M (host vector) may go out of scope
+  return RESNMTF_OK;
+}
+// CholeskyQR2: Y (in `a`) -> orthonormal columns (back in `a`, `b` is scratch) + f32 operand copy
+int orthonormalise(resnmtf_handle* h, InitScratch& sc, double* a, double* b, int len, int L, float* W32, int nt) {
+  std::vector<double> C, R, Ri;
+  for (int round = 0; round < 2; ++round) {
+    double* src = round == 0 ? a : b;
+    double* dst = round == 0 ? b : a;
+    if (int rc = ts_gram_host(h, sc, src, len, L, C)) return rc;
+    if (round == 0) {            // tiny ridge: random sketches of rank-deficient data stay factorable
+      double tr = 0.0;
+      for (int i = 0; i < L; ++i) tr += C[(size_t)i * L + i];
+      for (int i = 0; i < L; ++i) C[(size_t)i * L + i] += 1e-14 * tr;
+    }
+    if (!cholesky_upper(C, L, R)) return h->fail(RESNMTF_ERR_INVALID, "init_svd: sketch is rank deficient");
+    invert_upper(R, L, Ri);
+    if (int rc = ts_apply(h, sc, src, len, L, Ri, dst, round == 1 ? W32 : nullptr, nt)) return rc;
+  }
+  return RESNMTF_OK;
+}
+}  // namespace
+
+int resnmtf_init_svd(resnmtf_handle* h, int v, unsigned long long seed, double sigma, int n_power,
+                     double* singular_values) {
+  if (int rc = check_view(h, v)) return rc;
+  ViewState& vs = h->views[v];
+  if (!vs.owned || !vs.has_x) return h->fail(RESNMTF_ERR_STATE, "init_svd needs an owned view with data (set_view first)");
+  if (n_power < 1) n_power = 3;
+  if (!(sigma >= 0.0)) return h->fail(RESNMTF_ERR_INVALID, "sigma must be >= 0");
+  HIP_TRY(h, hipSetDevice(h->opt.device_id));
+  if (int rc = sync_both(h)) return rc;
+  const int n = vs.n, m = vs.m, k = vs.k;
+  const int L = std::min(64, 16 * ceil_div(k + 8, 16)), NTi = L / 16;
+  InitScratch sc;
+  hipError_t e;
+  auto alloc = [&](double** p, size_t cnt) { return hipMalloc(reinterpret_cast<void**>(p), cnt * sizeof(double)); };
+  if ((e = alloc(&sc.Yn, (size_t)n * L)) != hipSuccess || (e = alloc(&sc.Yn2, (size_t)n * L)) != hipSuccess ||
+      (e = alloc(&sc.Zm, (size_t)m * L)) != hipSuccess || (e = alloc(&sc.Zm2, (size_t)m * L)) != hipSuccess ||
+      (e = alloc(&sc.gpart, (size_t)(kGramBlocks + 1) * L * L)) != hipSuccess || (e = alloc(&sc.gram, (size_t)L * L)) != hipSuccess ||
+      (e = alloc(&sc.M, (size_t)L * L)) != hipSuccess)
+    return h->fail_hip("init_svd hipMalloc", e);
+  // slabs: the view's own when the sketch is as wide as its KP, else temporaries
+  if (L == vs.KP) { sc.Pn = vs.Pxg; sc.Pm = vs.Pxtf; }
+  else {
+    if ((e = hipMalloc(reinterpret_cast<void**>(&sc.Pn), (size_t)vs.nsplit_xg * vs.n_pad * L * sizeof(float))) != hipSuccess)
+      return h->fail_hip("init_svd hipMalloc slabs", e);
+    sc.own_pn = true;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&sc.Pm), (size_t)vs.nsplit_xtf * vs.m_pad * L * sizeof(float))) != hipSuccess)
+      return h->fail_hip("init_svd hipMalloc slabs", e);
+    sc.own_pm = true;
+  }
+  PassArgs xg{}, xt{};
+  xg.A = vs.Xt32; xg.lda = vs.ldxt; xg.ntiles = vs.n_pad / 64; xg.B = vs.G32; xg.ldb = 64; xg.P = sc.Pn;
+  xg.cols_pad = vs.n_pad; xg.rows_pad = vs.m_pad; xg.rows_per_split = vs.rps_xg; xg.nsplit = vs.nsplit_xg; xg.ctl = h->ctl;
+  xt.A = vs.X32; xt.lda = vs.ldx; xt.ntiles = vs.m_pad / 64; xt.B = vs.F32; xt.ldb = 64; xt.P = sc.Pm;
+  xt.cols_pad = vs.m_pad; xt.rows_pad = vs.n_pad; xt.rows_per_split = vs.rps_xtf; xt.nsplit = vs.nsplit_xtf; xt.ctl = h->ctl;
+
+  // Omega: m x L standard normal (host generator: the reference's RNG is not reproducible anyway)
+  std::mt19937_64 gen(seed);
+  std::normal_distribution<double> normal(0.0, 1.0);
+  std::vector<double> omega((size_t)m * L);
+  for (double& x : omega) x = normal(gen);
+  HIP_TRY(h, hipMemcpyAsync(sc.Zm, omega.data(), omega.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemsetAsync(vs.F32, 0, (size_t)vs.n_pad * 64 * sizeof(float), h->stream));
+  HIP_TRY(h, hipMemsetAsync(vs.G32, 0, (size_t)vs.m_pad * 64 * sizeof(float), h->stream));
+  hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(m * L, 256)), dim3(256), 0, h->stream, sc.Zm, m, L, vs.G32, 64, NTi);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (int it = 0; it < n_power; ++it) {
+    launch_pass_plain(h, xg, NTi, true);                                                   // Y = X Z
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(ceil_div(n * L, 256)), dim3(256), 0, h->stream, sc.Pn, vs.nsplit_xg, vs.n_pad, L, n, sc.Yn);
+    HIP_TRY(h, hipGetLastError());
+    if (int rc = orthonormalise(h, sc, sc.Yn, sc.Yn2, n, L, vs.F32, NTi)) return rc;          // Q (in Yn) + F32
+    launch_pass_plain(h, xt, NTi, false);                                                  // Z = X^T Q
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(ceil_div(m * L, 256)), dim3(256), 0, h->stream, sc.Pm, vs.nsplit_xtf, vs.m_pad, L, m, sc.Zm);
+    HIP_TRY(h, hipGetLastError());
+    if (it + 1 < n_power)
+      if (int rc = orthonormalise(h, sc, sc.Zm, sc.Zm2, m, L, vs.G32, NTi)) return rc;
+  }
+  // Z = X^T Q = V Sigma Ut^T  ->  Z^T Z = Ut Sigma^2 Ut^T;  U = Q Ut,  V = Z Ut Sigma^-1
+  std::vector<double> C, Ut;
+  if (int rc = ts_gram_host(h, sc, sc.Zm, m, L, C)) return rc;
+  jacobi_eigen(C, L, Ut);
+  std::vector<int> order(L);
+  for (int i = 0; i < L; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return C[(size_t)a * L + a] > C[(size_t)b * L + b]; });
+  std::vector<double> d(L), Mu((size_t)L * L), Mv((size_t)L * L);
+  for (int j = 0; j < L; ++j) {
+    const int src = order[j];
+    d[j] = std::sqrt(std::max(C[(size_t)src * L + src], 0.0));
+    for (int i = 0; i < L; ++i) {
+      Mu[(size_t)i * L + j] = Ut[(size_t)i * L + src];
+      Mv[(size_t)i * L + j] = d[j] > 0.0 ? Ut[(size_t)i * L + src] / d[j] : 0.0;
+    }
+  }
+  if (int rc = ts_apply(h, sc, sc.Yn, n, L, Mu, sc.Yn2, nullptr, NTi)) return rc;             // U (n x L)
+  if (int rc = ts_apply(h, sc, sc.Zm, m, L, Mv, sc.Zm2, nullptr, NTi)) return rc;             // V (m x L)
+  std::vector<double> U((size_t)n * L), V((size_t)m * L);
+  HIP_TRY(h, hipMemcpyAsync(U.data(), sc.Yn2, U.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(V.data(), sc.Zm2, V.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  // R/update_steps.r:93-115 on the k leading triplets (column-major outputs for set_factors)
+  std::vector<double> F0((size_t)n * k), G0((size_t)m * k), S0((size_t)k * k, 0.0), cf(k, 0.0), cg(k, 0.0), lam(k, 0.0), muv(k, 0.0);
+  for (int j = 0; j < k; ++j) {
+    for (int i = 0; i < n; ++i) { const double a = std::fabs(U[(size_t)i * L + j]); F0[(size_t)j * n + i] = a; cf[j] += a; }   // :93,:100
+    for (int i = 0; i < m; ++i) { const double a = std::fabs(V[(size_t)i * L + j]); G0[(size_t)j * m + i] = a; cg[j] += a; }   // :94,:101
+  }
+  std::normal_distribution<double> noise(0.0, std::sqrt(sigma));                    // mvrnorm(k, 0, sigma I), :96-99
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < k; ++i) {
+      double sv = (i == j ? std::fabs(d[j]) : 0.0);                                 // :95
+      if (sigma > 0.0) sv += std::fabs(noise(gen));
+      S0[(size_t)j * k + i] = sv * cf[j] * cg[j];                                   // :102-105 (column sweep)
+    }
+  for (int j = 0; j < k; ++j) {
+    for (int i = 0; i < n; ++i) { F0[(size_t)j * n + i] /= cf[j]; lam[j] += F0[(size_t)j * n + i]; }   // :106-109,:114
+    for (int i = 0; i < m; ++i) { G0[(size_t)j * m + i] /= cg[j]; muv[j] += G0[(size_t)j * m + i]; }   // :110-113,:115
+  }
+  if (singular_values)
+    for (int j = 0; j < k; ++j) singular_values[j] = d[j];
+  return resnmtf_set_factors(h, v, F0.data(), S0.data(), G0.data(), lam.data(), muv.data());
 }
 
 int resnmtf_set_restrictions(resnmtf_handle* h, const double* phi, const double* xi, const double* psi) {

@@ -112,6 +112,13 @@ class Engine:
         self._check(self._lib.resnmtf_set_view_raw(self._h, v, _dp(x), C.byref(neg)))
         return bool(neg.value)
 
+    def init_svd(self, v: int, seed: int = 0, sigma: float = 0.05, n_power: int = 0) -> np.ndarray:
+        """``init_mats_inner`` (``R/update_steps.r:78-125``) on the device for view ``v`` (randomized
+        top-k SVD on the streaming-pass kernels); returns the k leading singular values."""
+        d = np.zeros(self.k[v])
+        self._check(self._lib.resnmtf_init_svd(self._h, v, int(seed), float(sigma), int(n_power), _dp(d)))
+        return d
+
     def set_factors(self, v: int, f, s, g, lam=None, mu=None):
         k = self.k[v]
         f = _f64_colmajor(f, (self.n_rows[v], k))
