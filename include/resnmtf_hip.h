@@ -73,7 +73,10 @@ typedef struct resnmtf_options {
   int kk_mode;            /* where the k x k products come from: 0 auto, 1 = A (fp64 partials of the update
                              kernels, job in workgroup 0 of the pass launch), 2 = B (MFMA aux tiles, job in
                              the last-arriving aux workgroup); DESIGN.md section 4 */
-  int reserved[1];
+  int bf16_split;         /* 0 (default): the contractions use the exact f32 MFMA.  1: for k > 16 both operands
+                             are split into bf16 hi + lo and multiplied with three bf16 MFMAs (16 bits of
+                             mantissa): c5-sized views +31 % (the f32 MFMA pipe limits k > 32), F / G then
+                             within 1e-5 ... 6e-5 of the fp64 reference instead of 1e-6 ... 2e-5 */
 } resnmtf_options;
 
 typedef struct resnmtf_pass_timing {

@@ -31,7 +31,7 @@ class Options(C.Structure):
         ("use_graph", C.c_int), ("check_every", C.c_int), ("target_workgroups", C.c_int),
         ("time_kernels", C.c_int), ("pass_waves", C.c_int), ("pass_splits_xg", C.c_int),
         ("pass_splits_xtf", C.c_int), ("pass_lds_pad_kb", C.c_int), ("update_blocks", C.c_int),
-        ("no_pitch_pad", C.c_int), ("kk_mode", C.c_int), ("reserved", C.c_int * 1),
+        ("no_pitch_pad", C.c_int), ("kk_mode", C.c_int), ("bf16_split", C.c_int),
     ]
 
 

@@ -157,10 +157,15 @@ constexpr int kMaxLds = 160 * 1024;
 
 template <int NT, int NW, int UNROLL>
 hipError_t set_pass_attr() {
-  const void* fns[4] = {reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, false>),
+  constexpr bool BF = NT >= 2;      // (NT = 1 has no bf16 form: the two lists coincide)
+  const void* fns[8] = {reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, false>),
                         reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, false>),
                         reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, true>),
-                        reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, true>)};
+                        reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, true>),
+                        reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, false, BF>),
+                        reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, false, BF>),
+                        reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, true, BF>),
+                        reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, true, BF>)};
   for (const void* fn : fns) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     if (e != hipSuccess) return e;
@@ -222,9 +227,13 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
   // the elapsed time is the kernel's own begin->end, the same quantity rocprofv3 --kernel-trace reports
   const bool timed = h->opt.time_kernels && h->ev_used + 2 <= h->ev.size();
   hipEvent_t ev0 = timed ? h->ev[h->ev_used] : nullptr, ev1 = timed ? h->ev[h->ev_used + 1] : nullptr;
-#define LAUNCH_PASS_M(NTV, NWV, UV, XG, MA)                                                                              \
-  if (timed) hipExtLaunchKernelGGL((pass_kernel<NTV, NWV, UV, XG, MA>), grid, block, smem, h->stream, ev0, ev1, 0, a, kf, ks); \
-  else hipLaunchKernelGGL((pass_kernel<NTV, NWV, UV, XG, MA>), grid, block, smem, h->stream, a, kf, ks)
+  const bool bf = h->opt.bf16_split && v.NT >= 2;      // opt-in bf16 hi/lo MFMA form (k > 16), own instantiations
+#define LAUNCH_PASS_B(NTV, NWV, UV, XG, MA, BF)                                                                              \
+  if (timed) hipExtLaunchKernelGGL((pass_kernel<NTV, NWV, UV, XG, MA, BF>), grid, block, smem, h->stream, ev0, ev1, 0, a, kf, ks); \
+  else hipLaunchKernelGGL((pass_kernel<NTV, NWV, UV, XG, MA, BF>), grid, block, smem, h->stream, a, kf, ks)
+#define LAUNCH_PASS_M(NTV, NWV, UV, XG, MA)                                        \
+  if (bf && (NTV) >= 2) { LAUNCH_PASS_B(NTV, NWV, UV, XG, MA, ((NTV) >= 2)); }     \
+  else { LAUNCH_PASS_B(NTV, NWV, UV, XG, MA, false); }
 #define LAUNCH_PASS(NTV, NWV, UV)                                   \
   if (xg && a.kk_block0) { LAUNCH_PASS_M(NTV, NWV, UV, true, true); }      \
   else if (xg) { LAUNCH_PASS_M(NTV, NWV, UV, true, false); }               \
@@ -244,6 +253,7 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
   }
 #undef LAUNCH_PASS
 #undef LAUNCH_PASS_M
+#undef LAUNCH_PASS_B
   if (timed) {
     h->ev_kind[h->ev_used / 2] = xg ? 0 : 1;
     h->ev_used += 2;

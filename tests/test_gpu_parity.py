@@ -313,3 +313,22 @@ def test_device_svd_init_matches_oracle(shape, k):
     errs = e.run(20)
     e.close()
     assert np.isfinite(errs).all() and errs[-1] <= errs[0]
+
+
+@pytest.mark.parametrize("shapes,k,kw", [
+    ([(400, 300)], 48, {}),
+    ([(1000, 700)], 64, {}),
+    ([(300, 200), (300, 150)], 40, dict(phi=50.0, psi=0.0, xi=20.0)),
+    ([(700, 500)], 24, {}),
+])
+def test_bf16_split_option_stays_inside_the_bar(shapes, k, kw):
+    """resnmtf_options.bf16_split = 1 (opt-in, k > 16): both MFMA operands split into bf16 hi + lo, three
+    bf16 MFMAs per product (16 bits of mantissa instead of 24).  Tolerance here is the north-star bar
+    itself, 1e-4 rel-Frobenius on F and G (measured 1e-5 ... 6e-5); the default path is held to 2e-5."""
+    prob = synth.make_problem(shapes, k, **kw)
+    ref = run_oracle(prob, n_iters=30)
+    res = run_hip(prob, n_iters=30, bf16_split=True)
+    check_against(res, ref["output_f"], ref["output_s"], ref["output_g"], ref["row_clusters"], ref["col_clusters"],
+                  ref["All_Error"], tol_fg=1e-4)
+    exact = run_hip(prob, n_iters=30)
+    assert not np.array_equal(exact["output_f"][0], res["output_f"][0])        # the option really changes the arithmetic
