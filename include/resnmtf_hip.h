@@ -73,10 +73,13 @@ typedef struct resnmtf_options {
   int kk_mode;            /* where the k x k products come from: 0 auto, 1 = A (fp64 partials of the update
                              kernels, job in workgroup 0 of the pass launch), 2 = B (MFMA aux tiles, job in
                              the last-arriving aux workgroup); DESIGN.md section 4 */
-  int bf16_split;         /* 0 (default): the contractions use the exact f32 MFMA.  1: for k > 16 both operands
-                             are split into bf16 hi + lo and multiplied with three bf16 MFMAs (16 bits of
-                             mantissa): c5-sized views +31 % (the f32 MFMA pipe limits k > 32), F / G then
-                             within 1e-5 ... 6e-5 of the fp64 reference instead of 1e-6 ... 2e-5 */
+  int bf16_split;         /* MFMA form of the two big contractions for k > 16 (k <= 16 always uses the f32 MFMA):
+                             0 (default) both operands split in registers into THREE bf16 pieces, six bf16 MFMAs
+                               per product group -- dropped terms <= 2^-24: f32-grade, parity as the f32 MFMA,
+                               c5-sized view +14 % (the f32 MFMA pipe limits k > 32);
+                             1 TWO pieces, three MFMAs (16 bits of mantissa): c5 +45 %, F / G within
+                               1e-5 ... 6e-5 of the fp64 reference instead of 1e-6 ... 8e-6 (bar 1e-4);
+                             2 plain v_mfma_f32_16x16x4_f32 */
 } resnmtf_options;
 
 typedef struct resnmtf_pass_timing {

@@ -157,15 +157,19 @@ constexpr int kMaxLds = 160 * 1024;
 
 template <int NT, int NW, int UNROLL>
 hipError_t set_pass_attr() {
-  constexpr bool BF = NT >= 2;      // (NT = 1 has no bf16 form: the two lists coincide)
-  const void* fns[8] = {reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, false>),
-                        reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, false>),
-                        reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, true>),
-                        reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, true>),
-                        reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, false, BF>),
-                        reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, false, BF>),
-                        reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, true, BF>),
-                        reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, true, BF>)};
+  constexpr int S2 = NT >= 2 ? 2 : 0, S3 = NT >= 2 ? 3 : 0;      // (NT = 1 has no bf16 forms: the lists coincide)
+  const void* fns[12] = {reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, false>),
+                         reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, false>),
+                         reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, true>),
+                         reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, true>),
+                         reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, false, S2>),
+                         reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, false, S2>),
+                         reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, true, S2>),
+                         reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, true, S2>),
+                         reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, false, S3>),
+                         reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, false, S3>),
+                         reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, true, S3>),
+                         reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, true, S3>)};
   for (const void* fn : fns) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     if (e != hipSuccess) return e;
@@ -198,14 +202,13 @@ hipError_t set_all_attrs() {
   TRY_ATTR(set_smem_attrs<16>()); TRY_ATTR(set_smem_attrs<32>());
   TRY_ATTR(set_smem_attrs<48>()); TRY_ATTR(set_smem_attrs<64>());
   TRY_ATTR((set_pass_attr<1, 4, 8>())); TRY_ATTR((set_pass_attr<1, 8, 8>())); TRY_ATTR((set_pass_attr<1, 16, 8>()));
-  TRY_ATTR((set_pass_attr<2, 4, 4>())); TRY_ATTR((set_pass_attr<2, 8, 4>())); TRY_ATTR((set_pass_attr<2, 16, 4>()));
-  TRY_ATTR((set_pass_attr<3, 4, 4>())); TRY_ATTR((set_pass_attr<3, 8, 4>()));
-  TRY_ATTR((set_pass_attr<4, 4, 4>())); TRY_ATTR((set_pass_attr<4, 8, 4>()));
+  TRY_ATTR((set_pass_attr<2, 8, 4>())); TRY_ATTR((set_pass_attr<3, 8, 4>())); TRY_ATTR((set_pass_attr<4, 8, 4>()));
 #undef TRY_ATTR
   return hipSuccess;
 }
 
-int max_pass_waves(int NT) { return NT <= 2 ? 16 : 8; }
+// waves per workgroup: 8; k <= 16 also has 4- and 16-wave instantiations (tuning sweeps)
+int max_pass_waves(int NT) { return NT <= 1 ? 16 : 8; }
 // workgroups of a pass launch one CU holds at once: the kernels' __launch_bounds__ (kernels.hip.inc,
 // pass_min_blocks) keeps the k <= 32 instantiations within 128 VGPRs
 int pass_blocks_per_cu(int NT, int nw) { return pass_min_blocks(NT, nw); }
@@ -227,13 +230,16 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
   // the elapsed time is the kernel's own begin->end, the same quantity rocprofv3 --kernel-trace reports
   const bool timed = h->opt.time_kernels && h->ev_used + 2 <= h->ev.size();
   hipEvent_t ev0 = timed ? h->ev[h->ev_used] : nullptr, ev1 = timed ? h->ev[h->ev_used + 1] : nullptr;
-  const bool bf = h->opt.bf16_split && v.NT >= 2;      // opt-in bf16 hi/lo MFMA form (k > 16), own instantiations
-#define LAUNCH_PASS_B(NTV, NWV, UV, XG, MA, BF)                                                                              \
-  if (timed) hipExtLaunchKernelGGL((pass_kernel<NTV, NWV, UV, XG, MA, BF>), grid, block, smem, h->stream, ev0, ev1, 0, a, kf, ks); \
-  else hipLaunchKernelGGL((pass_kernel<NTV, NWV, UV, XG, MA, BF>), grid, block, smem, h->stream, a, kf, ks)
-#define LAUNCH_PASS_M(NTV, NWV, UV, XG, MA)                                        \
-  if (bf && (NTV) >= 2) { LAUNCH_PASS_B(NTV, NWV, UV, XG, MA, ((NTV) >= 2)); }     \
-  else { LAUNCH_PASS_B(NTV, NWV, UV, XG, MA, false); }
+  // MFMA form of the main tiles (resnmtf_options.bf16_split): k <= 16 always the f32 MFMA; k > 16: 0 =
+  // three-piece bf16 split (f32-grade, default), 1 = two-piece (16-bit mantissa, fastest), 2 = plain f32
+  const int split = v.NT < 2 ? 0 : (h->opt.bf16_split == 1 ? 2 : (h->opt.bf16_split == 2 ? 0 : 3));
+#define LAUNCH_PASS_B(NTV, NWV, UV, XG, MA, SP)                                                                              \
+  if (timed) hipExtLaunchKernelGGL((pass_kernel<NTV, NWV, UV, XG, MA, SP>), grid, block, smem, h->stream, ev0, ev1, 0, a, kf, ks); \
+  else hipLaunchKernelGGL((pass_kernel<NTV, NWV, UV, XG, MA, SP>), grid, block, smem, h->stream, a, kf, ks)
+#define LAUNCH_PASS_M(NTV, NWV, UV, XG, MA)                                              \
+  if (split == 3) { LAUNCH_PASS_B(NTV, NWV, UV, XG, MA, ((NTV) >= 2 ? 3 : 0)); }         \
+  else if (split == 2) { LAUNCH_PASS_B(NTV, NWV, UV, XG, MA, ((NTV) >= 2 ? 2 : 0)); }    \
+  else { LAUNCH_PASS_B(NTV, NWV, UV, XG, MA, 0); }
 #define LAUNCH_PASS(NTV, NWV, UV)                                   \
   if (xg && a.kk_block0) { LAUNCH_PASS_M(NTV, NWV, UV, true, true); }      \
   else if (xg) { LAUNCH_PASS_M(NTV, NWV, UV, true, false); }               \
@@ -243,12 +249,8 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
     case 104: LAUNCH_PASS(1, 4, 8); break;
     case 108: LAUNCH_PASS(1, 8, 8); break;
     case 116: LAUNCH_PASS(1, 16, 8); break;
-    case 204: LAUNCH_PASS(2, 4, 4); break;
     case 208: LAUNCH_PASS(2, 8, 4); break;
-    case 216: LAUNCH_PASS(2, 16, 4); break;
-    case 304: LAUNCH_PASS(3, 4, 4); break;
     case 308: LAUNCH_PASS(3, 8, 4); break;
-    case 404: LAUNCH_PASS(4, 4, 4); break;
     default: LAUNCH_PASS(4, 8, 4); break;
   }
 #undef LAUNCH_PASS
@@ -374,7 +376,7 @@ int flush_timing(resnmtf_handle* h) {
 void size_pass(int NT, int ntiles, int rows_pad, int slots, int max_nw, int force_nw, int force_ns,
                int* nsplit, int* rps, int* nw) {
   int w = std::min(8, max_nw);
-  if (force_nw == 4 || force_nw == 8 || force_nw == 16) w = std::min(force_nw, max_nw);
+  if (max_nw > 8 && (force_nw == 4 || force_nw == 8 || force_nw == 16)) w = force_nw;
   const int quantum = 4 * w * 8;                       // rows of one unrolled trip of a workgroup
   // streamed geometry: 16-step workgroups (512 rows); for k > 32 only about 8 workgroups per slot, i.e.
   // longer splits -- there the per-workgroup epilogue (tree sum of 64 accumulator registers per lane +
@@ -553,8 +555,7 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     if (o.kk_mode == 1) vs.kk_mode = 0;
     if (o.kk_mode == 2) vs.kk_mode = 1;
     // workgroup slots of a pass launch: target_workgroups overrides CUs x resident workgroups per CU
-    const int nw_guess = (o.pass_waves == 4 || o.pass_waves == 8 || o.pass_waves == 16)
-                             ? std::min(o.pass_waves, max_pass_waves(vs.NT)) : 8;
+    const int nw_guess = (vs.NT <= 1 && (o.pass_waves == 4 || o.pass_waves == 8 || o.pass_waves == 16)) ? o.pass_waves : 8;
     size_aux(vs.m_pad, nw_guess, &vs.nsaux_xg, &vs.rpsaux_xg);
     size_aux(vs.n_pad, nw_guess, &vs.nsaux_xtf, &vs.rpsaux_xtf);
     const int slots_all = o.target_workgroups > 0 ? o.target_workgroups : h->n_cu * pass_blocks_per_cu(vs.NT, nw_guess);

@@ -5,13 +5,15 @@ import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-from resnmtf_amd import naming, synth
+from resnmtf_amd import naming, synth, _lib
+if os.environ.get("LIB"):
+    _lib.LIB_PATH = os.environ["LIB"]
 from resnmtf_amd.engine import Engine
 
 ap = argparse.ArgumentParser()
 ap.add_argument("configs", nargs="*", default=["c2", "c3", "c4v1", "c5v1"])
 ap.add_argument("--sweeps", type=int, default=100)
-ap.add_argument("--bf16-split", action="store_true")
+ap.add_argument("--bf16-split", type=int, default=0)
 a = ap.parse_args()
 SHAPES = {
     "c2": ([(10000, 2000)], 16, {}),
