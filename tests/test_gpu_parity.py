@@ -335,3 +335,46 @@ def test_bf16_split_option_stays_inside_the_bar(shapes, k, kw):
                       ref["All_Error"], tol_fg=tol)
         outs[mode] = res["output_f"][0]
     assert not np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[0], outs[2])   # three distinct arithmetic forms
+
+
+@pytest.mark.parametrize("shape,k", [((5, 4), 2), ((17, 3), 3), ((63, 65), 2), ((64, 64), 16), ((3, 70), 2), ((200, 2), 2)])
+def test_tiny_and_ragged_shapes(shape, k):
+    """Edge sizes: far below one 64-wide tile, one past it, exactly one tile, three rows / two columns
+    (k >= 2: the reference itself fails for k = 1, Appendix B13)."""
+    prob = synth.make_problem([shape], k)
+    ref = run_oracle(prob, n_iters=25)
+    res = run_hip(prob, n_iters=25)
+    check_against(res, ref["output_f"], ref["output_s"], ref["output_g"], ref["row_clusters"], ref["col_clusters"],
+                  ref["All_Error"])
+
+
+def test_coupled_views_without_shared_names():
+    """Appendix B2: views coupled through phi / psi whose name sets are disjoint (the reference's NA maps,
+    R/utils.r:70): star_prod_relevant contributes nothing to the numerators, yet phi * F (psi * G) still
+    enters the denominators (R/update_steps.r:158, :200)."""
+    prob = synth.make_problem([(120, 90), (100, 90)], 4)
+    off = 1.0 - np.eye(2)
+    prob.phi, prob.psi = 5.0 * off, 3.0 * off
+    prob.row_names = [[f"a{i}" for i in range(120)], [f"b{i}" for i in range(100)]]      # no common row name
+    prob.col_names = [[f"c{j}" for j in range(90)], [f"d{j}" for j in range(90)]]        # no common column name
+    ref = run_oracle(prob, n_iters=40)
+    res = run_hip(prob, n_iters=40)
+    check_against(res, ref["output_f"], ref["output_s"], ref["output_g"], ref["row_clusters"], ref["col_clusters"],
+                  ref["All_Error"])
+    uncoupled = synth.make_problem([(120, 90), (100, 90)], 4)
+    free = run_hip(uncoupled, n_iters=40)
+    assert rel_fro(res["output_f"][0], free["output_f"][0]) > 1e-3        # the denominators did change the result
+
+
+def test_zero_rows_and_columns_in_x():
+    """A view with all-zero rows (legal: only the columns are normalised): the rows of F they feed go to
+    zero exactly as in the reference; the NaN -> 1 guard of the unrestricted branch keeps 0/0 quotients."""
+    prob = synth.make_problem([(150, 80)], 3)
+    x = prob.data[0].copy(); x[10:14, :] = 0.0
+    x = x / x.sum(axis=0)[None, :]
+    prob.data[0] = x
+    ref = run_oracle(prob, n_iters=40)
+    res = run_hip(prob, n_iters=40)
+    check_against(res, ref["output_f"], ref["output_s"], ref["output_g"], ref["row_clusters"], ref["col_clusters"],
+                  ref["All_Error"])
+    assert (res["output_f"][0][10:14] == 0).all() or np.allclose(res["output_f"][0][10:14], ref["output_f"][0][10:14], atol=1e-300)
