@@ -145,7 +145,8 @@ int resnmtf_set_factors(resnmtf_handle* h, int v, const double* F, const double*
  * whose big products are the streaming-pass kernels, and the noise from a std::mt19937_64 seeded with
  * `seed` (R's RNG / MASS::mvrnorm are not reproducible outside R): statistically, not bitwise,
  * equivalent; singular vectors of (near-)equal singular values are determined up to rotation in
- * either implementation.  sigma = 0.05 is the reference's default.  singular_values (k, may be NULL)
+ * either implementation.  Views whose short side is smaller than the sketch take an exact route instead
+ * (Gram matrix of the short side, Jacobi).  sigma = 0.05 is the reference's default.  singular_values (k, may be NULL)
  * receives d[1:k].  Requires resnmtf_set_view / resnmtf_set_view_raw; replaces resnmtf_set_factors.
  */
 int resnmtf_init_svd(resnmtf_handle* h, int v, unsigned long long seed, double sigma, int n_power,

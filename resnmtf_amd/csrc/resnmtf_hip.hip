@@ -821,6 +821,76 @@ int orthonormalise(resnmtf_handle* h, InitScratch& sc, double* a, double* b, int
 }
 }  // namespace
 
+namespace {
+// R/update_steps.r:93-115 on the k leading triplets: U (n x ldu), V (m x ldv) row-major, d descending.
+// Column-major outputs go through resnmtf_set_factors.
+int finish_init(resnmtf_handle* h, int v, const std::vector<double>& U, int ldu, const std::vector<double>& V, int ldv,
+                const std::vector<double>& d, double sigma, std::mt19937_64& gen, double* singular_values) {
+  const ViewState& vs = h->views[v];
+  const int n = vs.n, m = vs.m, k = vs.k;
+  std::vector<double> F0((size_t)n * k), G0((size_t)m * k), S0((size_t)k * k, 0.0), cf(k, 0.0), cg(k, 0.0), lam(k, 0.0), muv(k, 0.0);
+  for (int j = 0; j < k; ++j) {
+    for (int i = 0; i < n; ++i) { const double a = std::fabs(U[(size_t)i * ldu + j]); F0[(size_t)j * n + i] = a; cf[j] += a; }   // :93,:100
+    for (int i = 0; i < m; ++i) { const double a = std::fabs(V[(size_t)i * ldv + j]); G0[(size_t)j * m + i] = a; cg[j] += a; }   // :94,:101
+  }
+  std::normal_distribution<double> noise(0.0, std::sqrt(sigma));                    // mvrnorm(k, 0, sigma I), :96-99
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < k; ++i) {
+      double sv = (i == j ? std::fabs(d[j]) : 0.0);                                 // :95
+      if (sigma > 0.0) sv += std::fabs(noise(gen));
+      S0[(size_t)j * k + i] = sv * cf[j] * cg[j];                                   // :102-105 (column sweep)
+    }
+  for (int j = 0; j < k; ++j) {
+    for (int i = 0; i < n; ++i) { F0[(size_t)j * n + i] /= cf[j]; lam[j] += F0[(size_t)j * n + i]; }   // :106-109,:114
+    for (int i = 0; i < m; ++i) { G0[(size_t)j * m + i] /= cg[j]; muv[j] += G0[(size_t)j * m + i]; }   // :110-113,:115
+  }
+  if (singular_values)
+    for (int j = 0; j < k; ++j) singular_values[j] = d[j];
+  return resnmtf_set_factors(h, v, F0.data(), S0.data(), G0.data(), lam.data(), muv.data());
+}
+
+// Thin views (min(n, m) smaller than the sketch): the exact SVD through the Gram matrix of the short
+// side -- Y = X (m <= n) or X^T, C = Y^T Y (r x r, fp64, device), Jacobi on the host, the long-side
+// vectors Y W Sigma^-1 on the device.  No random sketch, no iteration.
+int init_svd_thin(resnmtf_handle* h, int v, double sigma, std::mt19937_64& gen, double* singular_values) {
+  ViewState& vs = h->views[v];
+  const int n = vs.n, m = vs.m;
+  const bool tall = m <= n;                       // Y = X [n][m]  or  X^T [m][n]
+  const int len = tall ? n : m, r = tall ? m : n;
+  InitScratch sc;
+  hipError_t e;
+  auto alloc = [&](double** p, size_t cnt) { return hipMalloc(reinterpret_cast<void**>(p), cnt * sizeof(double)); };
+  if ((e = alloc(&sc.Yn, (size_t)len * r)) != hipSuccess || (e = alloc(&sc.Yn2, (size_t)len * r)) != hipSuccess ||
+      (e = alloc(&sc.gpart, (size_t)(kGramBlocks + 1) * r * r)) != hipSuccess || (e = alloc(&sc.gram, (size_t)r * r)) != hipSuccess ||
+      (e = alloc(&sc.M, (size_t)r * r)) != hipSuccess)
+    return h->fail_hip("init_svd hipMalloc", e);
+  hipLaunchKernelGGL(widen_rows_kernel, dim3(ceil_div(len * r, 256)), dim3(256), 0, h->stream, tall ? vs.X32 : vs.Xt32,
+                     tall ? vs.ldx : vs.ldxt, len, r, sc.Yn);
+  HIP_TRY(h, hipGetLastError());
+  std::vector<double> C, W;
+  if (int rc = ts_gram_host(h, sc, sc.Yn, len, r, C)) return rc;
+  jacobi_eigen(C, r, W);
+  std::vector<int> order(r);
+  for (int i = 0; i < r; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return C[(size_t)a * r + a] > C[(size_t)b * r + b]; });
+  std::vector<double> d(r), Ws((size_t)r * r), Wn((size_t)r * r);
+  for (int j = 0; j < r; ++j) {
+    const int src = order[j];
+    d[j] = std::sqrt(std::max(C[(size_t)src * r + src], 0.0));
+    for (int i = 0; i < r; ++i) {
+      Ws[(size_t)i * r + j] = W[(size_t)i * r + src];
+      Wn[(size_t)i * r + j] = d[j] > 0.0 ? W[(size_t)i * r + src] / d[j] : 0.0;
+    }
+  }
+  if (int rc = ts_apply(h, sc, sc.Yn, len, r, Wn, sc.Yn2, nullptr, 1)) return rc;     // long-side vectors
+  std::vector<double> Lg((size_t)len * r);
+  HIP_TRY(h, hipMemcpyAsync(Lg.data(), sc.Yn2, Lg.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return tall ? finish_init(h, v, Lg, r, Ws, r, d, sigma, gen, singular_values)
+              : finish_init(h, v, Ws, r, Lg, r, d, sigma, gen, singular_values);
+}
+}  // namespace
+
 int resnmtf_init_svd(resnmtf_handle* h, int v, unsigned long long seed, double sigma, int n_power,
                      double* singular_values) {
   if (int rc = check_view(h, v)) return rc;
@@ -832,6 +902,8 @@ int resnmtf_init_svd(resnmtf_handle* h, int v, unsigned long long seed, double s
   if (int rc = sync_both(h)) return rc;
   const int n = vs.n, m = vs.m, k = vs.k;
   const int L = std::min(64, 16 * ceil_div(k + 8, 16)), NTi = L / 16;
+  std::mt19937_64 gen(seed);
+  if (std::min(n, m) < L) return init_svd_thin(h, v, sigma, gen, singular_values);
   InitScratch sc;
   hipError_t e;
   auto alloc = [&](double** p, size_t cnt) { return hipMalloc(reinterpret_cast<void**>(p), cnt * sizeof(double)); };
@@ -857,7 +929,6 @@ int resnmtf_init_svd(resnmtf_handle* h, int v, unsigned long long seed, double s
   xt.cols_pad = vs.m_pad; xt.rows_pad = vs.n_pad; xt.rows_per_split = vs.rps_xtf; xt.nsplit = vs.nsplit_xtf; xt.ctl = h->ctl;
 
   // Omega: m x L standard normal (host generator: the reference's RNG is not reproducible anyway)
-  std::mt19937_64 gen(seed);
   std::normal_distribution<double> normal(0.0, 1.0);
   std::vector<double> omega((size_t)m * L);
   for (double& x : omega) x = normal(gen);
@@ -899,26 +970,7 @@ int resnmtf_init_svd(resnmtf_handle* h, int v, unsigned long long seed, double s
   HIP_TRY(h, hipMemcpyAsync(U.data(), sc.Yn2, U.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(V.data(), sc.Zm2, V.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  // R/update_steps.r:93-115 on the k leading triplets (column-major outputs for set_factors)
-  std::vector<double> F0((size_t)n * k), G0((size_t)m * k), S0((size_t)k * k, 0.0), cf(k, 0.0), cg(k, 0.0), lam(k, 0.0), muv(k, 0.0);
-  for (int j = 0; j < k; ++j) {
-    for (int i = 0; i < n; ++i) { const double a = std::fabs(U[(size_t)i * L + j]); F0[(size_t)j * n + i] = a; cf[j] += a; }   // :93,:100
-    for (int i = 0; i < m; ++i) { const double a = std::fabs(V[(size_t)i * L + j]); G0[(size_t)j * m + i] = a; cg[j] += a; }   // :94,:101
-  }
-  std::normal_distribution<double> noise(0.0, std::sqrt(sigma));                    // mvrnorm(k, 0, sigma I), :96-99
-  for (int j = 0; j < k; ++j)
-    for (int i = 0; i < k; ++i) {
-      double sv = (i == j ? std::fabs(d[j]) : 0.0);                                 // :95
-      if (sigma > 0.0) sv += std::fabs(noise(gen));
-      S0[(size_t)j * k + i] = sv * cf[j] * cg[j];                                   // :102-105 (column sweep)
-    }
-  for (int j = 0; j < k; ++j) {
-    for (int i = 0; i < n; ++i) { F0[(size_t)j * n + i] /= cf[j]; lam[j] += F0[(size_t)j * n + i]; }   // :106-109,:114
-    for (int i = 0; i < m; ++i) { G0[(size_t)j * m + i] /= cg[j]; muv[j] += G0[(size_t)j * m + i]; }   // :110-113,:115
-  }
-  if (singular_values)
-    for (int j = 0; j < k; ++j) singular_values[j] = d[j];
-  return resnmtf_set_factors(h, v, F0.data(), S0.data(), G0.data(), lam.data(), muv.data());
+  return finish_init(h, v, U, L, V, L, d, sigma, gen, singular_values);
 }
 
 int resnmtf_set_restrictions(resnmtf_handle* h, const double* phi, const double* xi, const double* psi) {

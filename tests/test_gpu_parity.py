@@ -378,3 +378,24 @@ def test_zero_rows_and_columns_in_x():
     check_against(res, ref["output_f"], ref["output_s"], ref["output_g"], ref["row_clusters"], ref["col_clusters"],
                   ref["All_Error"])
     assert (res["output_f"][0][10:14] == 0).all() or np.allclose(res["output_f"][0][10:14], ref["output_f"][0][10:14], atol=1e-300)
+
+
+@pytest.mark.parametrize("shape,k", [((5, 4), 2), ((17, 3), 3), ((30, 20), 10), ((200, 12), 12), ((9, 500), 4)])
+def test_device_svd_init_thin_views(shape, k):
+    """Views whose short side is smaller than the random sketch take the exact route (Gram of the short
+    side on the device, Jacobi on the host): same outputs as the oracle's full-SVD init_mats_inner."""
+    from oracle import resnmtf_oracle as O
+    from resnmtf_amd.engine import Engine
+    n, m = shape
+    x = _distinct_blocks(n, m, min(k, 3), 9) if min(n, m) >= 6 else synth.planted_view(n, m, k, 7)
+    rf, rs, rg, rlam, rmu = O.init_mats_inner([x], [k], np.random.default_rng(0), sigma=0.0)
+    d_ref = np.linalg.svd(x, compute_uv=False)[:k]
+    e = Engine([n], [m], [k]); e.set_view(0, x); e.set_restrictions()
+    d = e.init_svd(0, seed=1, sigma=0.0)
+    f0, s0, g0, lam, mu = e.get_factors(0)
+    e.close()
+    # X lives on the device in fp32 and the Gram squares the condition number: the smallest of the k
+    # triplets of a full-rank thin view is the least accurate
+    np.testing.assert_allclose(d, d_ref, rtol=1e-5, atol=1e-7 * d_ref[0])
+    strong = d_ref > 1e-3 * d_ref[0]
+    assert rel_fro(f0[:, strong], rf[0][:, strong]) < 1e-4 and rel_fro(g0[:, strong], rg[0][:, strong]) < 1e-4
