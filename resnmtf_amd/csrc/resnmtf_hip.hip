@@ -37,6 +37,7 @@ struct SharedMap {
   bool set = false;        // false or count < 0  ->  NA
   int count = -1;
   int* dev = nullptr;      // [len_v] row of w or -1
+  bool identity = false;   // every row of v maps to the same row of w (auto-named views): no lookup needed
 };
 
 struct ViewState {
@@ -184,14 +185,22 @@ hipError_t set_smem_attrs() {
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fn), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                (int)(bytes))) != hipSuccess)                                                   \
   return e
-  SET_ATTR((factor_update_kernel<KP, false, false, false>), update_smem_bytes(KP));
-  SET_ATTR((factor_update_kernel<KP, false, true, false>), update_smem_bytes(KP));
-  SET_ATTR((factor_update_kernel<KP, true, false, false>), update_smem_bytes(KP));
-  SET_ATTR((factor_update_kernel<KP, true, true, false>), update_smem_bytes(KP));
-  SET_ATTR((factor_update_kernel<KP, false, false, true>), update_smem_bytes(KP));
-  SET_ATTR((factor_update_kernel<KP, false, true, true>), update_smem_bytes(KP));
-  SET_ATTR((factor_update_kernel<KP, true, false, true>), update_smem_bytes(KP));
-  SET_ATTR((factor_update_kernel<KP, true, true, true>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, false, 0, false>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, false, 4, false>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, false, 8, false>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, false, RESNMTF_MAX_COUPLE, false>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, true, 0, false>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, true, 4, false>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, true, 8, false>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, true, RESNMTF_MAX_COUPLE, false>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, false, 0, true>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, false, 4, true>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, false, 8, true>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, false, RESNMTF_MAX_COUPLE, true>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, true, 0, true>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, true, 4, true>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, true, 8, true>), update_smem_bytes(KP));
+  SET_ATTR((factor_update_kernel<KP, true, RESNMTF_MAX_COUPLE, true>), update_smem_bytes(KP));
 #undef SET_ATTR
   return hipSuccess;
 }
@@ -290,14 +299,18 @@ void launch_update(resnmtf_handle* h, const ViewState& v, int kind, bool check_d
   const int nblk = kind == 0 ? v.nblkF : v.nblkG;
   const size_t smem = update_smem_bytes(v.KP);
   const bool emit = v.kk_mode == 0;
+  // coupling-count bucket of the kernel instantiation: 0 = unrestricted form, else room for 4, 8 or 16 coupled views
 #define LAUNCH_UPD_K(KPV, G_, C_)                                                                                      \
   if (emit) hipLaunchKernelGGL((factor_update_kernel<KPV, G_, C_, true>), dim3(nblk), dim3(UPDATE_THREADS), smem, h->stream, a); \
   else hipLaunchKernelGGL((factor_update_kernel<KPV, G_, C_, false>), dim3(nblk), dim3(UPDATE_THREADS), smem, h->stream, a)
-#define LAUNCH_UPD(KPV)                                                      \
-  if (kind == 0 && a.restricted) { LAUNCH_UPD_K(KPV, false, true); }         \
-  else if (kind == 0) { LAUNCH_UPD_K(KPV, false, false); }                   \
-  else if (a.restricted) { LAUNCH_UPD_K(KPV, true, true); }                  \
-  else { LAUNCH_UPD_K(KPV, true, false); }
+#define LAUNCH_UPD_C(KPV, G_)                                               \
+  if (!a.restricted) { LAUNCH_UPD_K(KPV, G_, 0); }                          \
+  else if (a.n_couple <= 4) { LAUNCH_UPD_K(KPV, G_, 4); }                   \
+  else if (a.n_couple <= 8) { LAUNCH_UPD_K(KPV, G_, 8); }                   \
+  else { LAUNCH_UPD_K(KPV, G_, RESNMTF_MAX_COUPLE); }
+#define LAUNCH_UPD(KPV)                                  \
+  if (kind == 0) { LAUNCH_UPD_C(KPV, false); }           \
+  else { LAUNCH_UPD_C(KPV, true); }
   switch (v.NT) {
     case 1: LAUNCH_UPD(16); break;
     case 2: LAUNCH_UPD(32); break;
@@ -305,6 +318,7 @@ void launch_update(resnmtf_handle* h, const ViewState& v, int kind, bool check_d
     default: LAUNCH_UPD(64); break;
   }
 #undef LAUNCH_UPD
+#undef LAUNCH_UPD_C
 #undef LAUNCH_UPD_K
 }
 
@@ -1016,6 +1030,8 @@ static int set_shared(resnmtf_handle* h, int v, int w, int count, const int* idx
   if (!mp.dev) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&mp.dev), (size_t)len_v * sizeof(int)));
   HIP_TRY(h, hipMemcpy(mp.dev, map.data(), (size_t)len_v * sizeof(int), hipMemcpyHostToDevice));
   mp.set = true; mp.count = count;
+  mp.identity = true;
+  for (int r = 0; r < len_v && mp.identity; ++r) mp.identity = map[r] == r;
   return RESNMTF_OK;
 }
 
@@ -1072,7 +1088,7 @@ static int build_args(resnmtf_handle* h) {
         if (!mp.set || mp.count < 0) continue;                                     // NA: utils.r:70
         if (h->views[i].k != vs.k) return h->fail(RESNMTF_ERR_INVALID, "phi-coupled views need equal k");
         CoupleDesc& c = f.couple[f.n_couple++];
-        c.W = h->views[i].F; c.map = mp.dev; c.weight = wgt; c.n_other = (double)h->views[i].n;
+        c.W = h->views[i].F; c.map = mp.identity ? nullptr : mp.dev; c.weight = wgt; c.n_other = (double)h->views[i].n;
       }
     }
     // --- G update (R/update_steps.r:180-207); branch on the WHOLE psi matrix (:190)
@@ -1095,7 +1111,7 @@ static int build_args(resnmtf_handle* h) {
         if (!mp.set || mp.count < 0) continue;
         if (h->views[i].k != vs.k) return h->fail(RESNMTF_ERR_INVALID, "psi-coupled views need equal k");
         CoupleDesc& c = g.couple[g.n_couple++];
-        c.W = h->views[i].G; c.map = mp.dev; c.weight = wgt; c.n_other = (double)h->views[i].m;
+        c.W = h->views[i].G; c.map = mp.identity ? nullptr : mp.dev; c.weight = wgt; c.n_other = (double)h->views[i].m;
       }
     }
     // --- k x k side kernels
