@@ -154,8 +154,8 @@ def run_sharded(args) -> dict:
     n, m, k = 10000, 2000, 16
     # every rank builds only the view it owns (same seeds as synth.make_problem) + all initial factors
     prob = sharded.local_problem(n_views, (n, m), k, phi=200.0, owned=[rank])
-    drv = sharded.ShardedSweep(prob, owner_of=list(range(n_views)), rank=rank, world=world,
-                               device_index=local_rank)
+    drv = sharded.ShardedSweep(prob, owner_of=list(range(n_views)), rank=rank, world=world, device_index=local_rank,
+                               replicate_f=(os.environ.get("RESNMTF_NO_REPLICATE") != "1"))
     if os.environ.get("RESNMTF_FORCE_BCAST") == "1":      # rehearsal: issue the F broadcast even with one rank
         drv.plan[0]["F"] = True
     drv.run(args.warmup)
@@ -168,6 +168,7 @@ def run_sharded(args) -> dict:
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     errs = drv.mean_errors()
+    replicated = any(drv.replicated)
     drv.close()
     dist.destroy_process_group()
     if rank != 0:
@@ -176,8 +177,9 @@ def run_sharded(args) -> dict:
         "metric": METRIC, "value": round(args.steps * n_views / dt, 2), "unit": "view-updates/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{n_views} phi-coupled views 10000x2000 (all rows shared, phi=200), k=16, one view "
-                               "per GPU, F exchanged by ordered RCCL broadcasts (Gauss-Seidel order)",
+        "config": {"workload": f"{n_views} phi-coupled views 10000x2000 (all rows shared, phi=200), k=16, one view per GPU, "
+                               + ("F chain replicated on every rank (its inputs broadcast once per sweep over RCCL), "
+                                  if replicated else "F exchanged by ordered RCCL broadcasts, ") + "Gauss-Seidel order kept exactly",
                    "n_views": n_views, "rows": n, "cols": m, "k": k,
                    "final_error": float(errs[-1]) if len(errs) else None},
         "roofline": None, "cpu_baseline": None,

@@ -42,7 +42,8 @@ enum {
 };
 
 /* factor selectors for resnmtf_factor_device_ptr */
-enum { RESNMTF_FACTOR_F = 0, RESNMTF_FACTOR_G = 1, RESNMTF_FACTOR_S = 2 };
+enum { RESNMTF_FACTOR_F = 0, RESNMTF_FACTOR_G = 1, RESNMTF_FACTOR_S = 2,
+       RESNMTF_FACTOR_FBLOCK = 3 /* replicate_f: the F update's inputs [U slabs | Ma_F | Md_F | lambda], contiguous */ };
 
 /* phases of one view's update inside a sweep (R/update_steps.r:282-314) */
 enum {
@@ -80,6 +81,12 @@ typedef struct resnmtf_options {
                              1 TWO pieces, three MFMAs (16 bits of mantissa): c5 +45 %, F / G within
                                1e-5 ... 6e-5 of the fp64 reference instead of 1e-6 ... 8e-6 (bar 1e-4);
                              2 plain v_mfma_f32_16x16x4_f32 */
+  int replicate_f;        /* view-sharded use (phase API): 1 = every rank keeps, for EVERY view, the inputs of its F
+                             update (the X.G slabs, the two k x k coefficient matrices, lambda) in one contiguous
+                             exchange block (RESNMTF_FACTOR_FBLOCK) and may run RESNMTF_PHASE_F on views it does
+                             not own: the host broadcasts the block after the owner's PHASE_G and every rank
+                             computes the phi-coupled F chain locally -- identical kernels on identical bytes,
+                             so bitwise the same F everywhere -- instead of waiting for N serial F broadcasts */
 } resnmtf_options;
 
 typedef struct resnmtf_pass_timing {

@@ -54,6 +54,9 @@ struct ViewState {
   float *Pxg = nullptr, *Pxtf = nullptr, *Paux_xg = nullptr, *Paux_xtf = nullptr;
   int *cnt_xg = nullptr, *cnt_xtf = nullptr;
   int rpbF = 16, nblkF = 1, rpbG = 16, nblkG = 1;
+  void* fblk = nullptr;              // replicate_f: [Pxg slabs | Ma_F | Md_F | lambda] contiguous (the F-update's inputs)
+  size_t fblk_bytes = 0;
+  bool f_replica = false;            // non-owned view whose F update runs here too (replicate_f)
   int kk_mode = 0;                   // 0 = A: Gram partials from the update kernels, k x k job = workgroup 0
                                      // 1 = B: Gram/cross/colsum on MFMA aux tiles, k x k job = last-arriving aux workgroup
   double *partF = nullptr, *partG = nullptr;
@@ -119,6 +122,7 @@ hipError_t dev_alloc_zero(T** p, size_t count) {
 }
 
 void free_view(ViewState& v) {
+  if (v.fblk) { (void)hipFree(v.fblk); v.fblk = nullptr; v.Pxg = nullptr; v.Ma_F = nullptr; v.Md_F = nullptr; v.lambda = nullptr; }
   void* ptrs[] = {v.X32, v.Xt32, v.xnorm2, v.F, v.G, v.S, v.lambda, v.mu, v.F32, v.G32, v.T32, v.Pxg, v.Pxtf,
                   v.Paux_xg, v.Paux_xtf, v.cnt_xg, v.cnt_xtf, v.partF, v.partG, v.FtF, v.FtFS, v.cF, v.Ma_F, v.Md_F, v.Ma_G, v.Md_G};
   for (void* p : ptrs)
@@ -434,6 +438,7 @@ int ensure_err_capacity(resnmtf_handle* h, int sweeps) {
   h->err = nullptr;
   const int cap = std::max(sweeps, 1024);
   hipError_t e = dev_alloc_zero(&h->err, (size_t)cap * h->V);
+  if (e == hipSuccess) e = hipDeviceSynchronize();      // (NULL-stream memset vs the handle's non-blocking stream)
   if (e != hipSuccess) { h->err_cap = 0; return h->fail_hip("hipMalloc err", e); }
   h->err_cap = cap;
   h->prepared = false;   // kernel argument blocks hold the pointer
@@ -544,20 +549,7 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     if ((e = dev_alloc_zero(&vs.F, (size_t)vs.n * vs.k)) != hipSuccess) return bail(e, "hipMalloc F");
     if ((e = dev_alloc_zero(&vs.G, (size_t)vs.m * vs.k)) != hipSuccess) return bail(e, "hipMalloc G");
     if ((e = dev_alloc_zero(&vs.S, kk)) != hipSuccess) return bail(e, "hipMalloc S");
-    if (!vs.owned) continue;
-    if ((e = dev_alloc_zero(&vs.lambda, (size_t)vs.k)) != hipSuccess) return bail(e, "hipMalloc lambda");
-    if ((e = dev_alloc_zero(&vs.mu, (size_t)vs.k)) != hipSuccess) return bail(e, "hipMalloc mu");
-    if ((e = dev_alloc_zero(&vs.xnorm2, 1)) != hipSuccess) return bail(e, "hipMalloc xnorm2");
-    if ((e = dev_alloc_zero(&vs.X32, (size_t)vs.n_pad * vs.ldx)) != hipSuccess) return bail(e, "hipMalloc X32");
-    if ((e = dev_alloc_zero(&vs.Xt32, (size_t)vs.m_pad * vs.ldxt)) != hipSuccess) return bail(e, "hipMalloc Xt32");
-    if ((e = dev_alloc_zero(&vs.F32, (size_t)vs.n_pad * 64)) != hipSuccess) return bail(e, "hipMalloc F32");
-    if ((e = dev_alloc_zero(&vs.G32, (size_t)vs.m_pad * 64)) != hipSuccess) return bail(e, "hipMalloc G32");
-    if ((e = dev_alloc_zero(&vs.T32, (size_t)vs.m_pad * 64)) != hipSuccess) return bail(e, "hipMalloc T32");
-    if ((e = dev_alloc_zero(&vs.cnt_xg, 4)) != hipSuccess) return bail(e, "hipMalloc cnt");
-    if ((e = dev_alloc_zero(&vs.cnt_xtf, 4)) != hipSuccess) return bail(e, "hipMalloc cnt");
-    for (double** pp : {&vs.FtF, &vs.FtFS, &vs.Ma_F, &vs.Md_F, &vs.Ma_G, &vs.Md_G})
-      if ((e = dev_alloc_zero(pp, kk)) != hipSuccess) return bail(e, "hipMalloc kxk");
-    if ((e = dev_alloc_zero(&vs.cF, (size_t)vs.k)) != hipSuccess) return bail(e, "hipMalloc cF");
+    // ---- geometry (identical on every rank for a given view: n, m, k and the options decide it)
     // k x k mode (kernels.hip.inc, pass_kernel).  A (k <= 16): the update kernels emit fp64 partial
     // Grams (1-4 KB per workgroup), the job is workgroup 0 of the next pass launch and runs beside the
     // whole pass.  B (k > 16, where those partials would be 8-32 KB per workgroup): MFMA aux tiles in
@@ -579,10 +571,6 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
               &vs.nsplit_xg, &vs.rps_xg, &vs.nw_xg);
     size_pass(vs.NT, vs.m_pad / 64, vs.n_pad, slots_xtf, max_pass_waves(vs.NT), o.pass_waves, o.pass_splits_xtf,
               &vs.nsplit_xtf, &vs.rps_xtf, &vs.nw_xtf);
-    if ((e = dev_alloc_zero(&vs.Pxg, (size_t)vs.nsplit_xg * vs.n_pad * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Pxg");
-    if ((e = dev_alloc_zero(&vs.Pxtf, (size_t)vs.nsplit_xtf * vs.m_pad * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Pxtf");
-    if ((e = dev_alloc_zero(&vs.Paux_xg, (size_t)3 * vs.nsaux_xg * 64 * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Paux");
-    if ((e = dev_alloc_zero(&vs.Paux_xtf, (size_t)2 * vs.nsaux_xtf * 64 * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Paux");
     const int RG = UPDATE_THREADS / vs.KP;
     // update workgroups: mode A ~160 (few partials for the k x k job, two prefetched row groups each
     // at c2 -- tools/tune_c2.py); mode B one row group per workgroup up to 1024 workgroups (a single
@@ -590,13 +578,57 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     const int nblk_target = o.update_blocks > 0 ? o.update_blocks : (vs.kk_mode == 0 ? (xbytes <= ((size_t)256 << 20) ? 160 : 512) : 1024);
     vs.rpbF = round_up(std::max(RG, ceil_div(vs.n, nblk_target)), RG); vs.nblkF = ceil_div(vs.n, vs.rpbF);
     vs.rpbG = round_up(std::max(RG, ceil_div(vs.m, nblk_target)), RG); vs.nblkG = ceil_div(vs.m, vs.rpbG);
+    const size_t kkp = (size_t)vs.KP * vs.KP;
+    // ---- the F update's inputs.  replicate_f: one contiguous exchange block per view, on every rank
+    // (the sharded driver broadcasts it from the owner and runs the F update of coupled views everywhere)
+    const size_t pxg_floats = (size_t)vs.nsplit_xg * vs.n_pad * vs.KP;
+    if (o.replicate_f) {
+      const size_t pxg_bytes = (pxg_floats * sizeof(float) + 255) / 256 * 256;
+      vs.fblk_bytes = pxg_bytes + (2 * kk + (size_t)vs.k) * sizeof(double);
+      if ((e = hipMalloc(&vs.fblk, vs.fblk_bytes)) != hipSuccess) return bail(e, "hipMalloc F exchange block");
+      if ((e = hipMemset(vs.fblk, 0, vs.fblk_bytes)) != hipSuccess) return bail(e, "hipMemset F exchange block");
+      char* base = static_cast<char*>(vs.fblk);
+      vs.Pxg = reinterpret_cast<float*>(base);
+      vs.Ma_F = reinterpret_cast<double*>(base + pxg_bytes);
+      vs.Md_F = vs.Ma_F + kk;
+      vs.lambda = vs.Md_F + kk;
+      if (!vs.owned) {
+        vs.f_replica = true;
+        if ((e = dev_alloc_zero(&vs.F32, (size_t)vs.n_pad * 64)) != hipSuccess) return bail(e, "hipMalloc F32");
+        if (vs.kk_mode == 0 && (e = dev_alloc_zero(&vs.partF, (size_t)vs.nblkF * (kkp + vs.KP))) != hipSuccess) return bail(e, "hipMalloc partF");
+      }
+    }
+    if (!vs.owned) continue;
+    if (!o.replicate_f) {
+      if ((e = dev_alloc_zero(&vs.lambda, (size_t)vs.k)) != hipSuccess) return bail(e, "hipMalloc lambda");
+      if ((e = dev_alloc_zero(&vs.Pxg, pxg_floats)) != hipSuccess) return bail(e, "hipMalloc Pxg");
+      for (double** pp : {&vs.Ma_F, &vs.Md_F})
+        if ((e = dev_alloc_zero(pp, kk)) != hipSuccess) return bail(e, "hipMalloc kxk");
+    }
+    if ((e = dev_alloc_zero(&vs.mu, (size_t)vs.k)) != hipSuccess) return bail(e, "hipMalloc mu");
+    if ((e = dev_alloc_zero(&vs.xnorm2, 1)) != hipSuccess) return bail(e, "hipMalloc xnorm2");
+    if ((e = dev_alloc_zero(&vs.X32, (size_t)vs.n_pad * vs.ldx)) != hipSuccess) return bail(e, "hipMalloc X32");
+    if ((e = dev_alloc_zero(&vs.Xt32, (size_t)vs.m_pad * vs.ldxt)) != hipSuccess) return bail(e, "hipMalloc Xt32");
+    if ((e = dev_alloc_zero(&vs.F32, (size_t)vs.n_pad * 64)) != hipSuccess) return bail(e, "hipMalloc F32");
+    if ((e = dev_alloc_zero(&vs.G32, (size_t)vs.m_pad * 64)) != hipSuccess) return bail(e, "hipMalloc G32");
+    if ((e = dev_alloc_zero(&vs.T32, (size_t)vs.m_pad * 64)) != hipSuccess) return bail(e, "hipMalloc T32");
+    if ((e = dev_alloc_zero(&vs.cnt_xg, 4)) != hipSuccess) return bail(e, "hipMalloc cnt");
+    if ((e = dev_alloc_zero(&vs.cnt_xtf, 4)) != hipSuccess) return bail(e, "hipMalloc cnt");
+    for (double** pp : {&vs.FtF, &vs.FtFS, &vs.Ma_G, &vs.Md_G})
+      if ((e = dev_alloc_zero(pp, kk)) != hipSuccess) return bail(e, "hipMalloc kxk");
+    if ((e = dev_alloc_zero(&vs.cF, (size_t)vs.k)) != hipSuccess) return bail(e, "hipMalloc cF");
+    if ((e = dev_alloc_zero(&vs.Pxtf, (size_t)vs.nsplit_xtf * vs.m_pad * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Pxtf");
+    if ((e = dev_alloc_zero(&vs.Paux_xg, (size_t)3 * vs.nsaux_xg * 64 * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Paux");
+    if ((e = dev_alloc_zero(&vs.Paux_xtf, (size_t)2 * vs.nsaux_xtf * 64 * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Paux");
     if (vs.kk_mode == 0) {
-      const size_t kkp = (size_t)vs.KP * vs.KP;
       if ((e = dev_alloc_zero(&vs.partF, (size_t)vs.nblkF * (kkp + vs.KP))) != hipSuccess) return bail(e, "hipMalloc partF");
       if ((e = dev_alloc_zero(&vs.partG, (size_t)vs.nblkG * (2 * kkp + vs.KP))) != hipSuccess) return bail(e, "hipMalloc partG");
     }
   }
   if ((e = set_all_attrs()) != hipSuccess) return bail(e, "hipFuncSetAttribute");
+  // the zero fills above ran on the NULL stream, which the handle's (non-blocking) stream does not wait
+  // for: finish them before anything is enqueued there (a late memset would wipe uploaded data)
+  if ((e = hipDeviceSynchronize()) != hipSuccess) return bail(e, "hipDeviceSynchronize");
   if (o.time_kernels) {
     h->ev.resize(8192);
     h->ev_kind.resize(4096);
@@ -1051,23 +1083,7 @@ static int build_args(resnmtf_handle* h) {
   for (int v = 0; v < V; ++v) {
     ViewState& vs = h->views[v];
     if (!vs.has_factors) return h->fail(RESNMTF_ERR_STATE, "set_factors missing for a view");
-    if (!vs.owned) continue;
-    if (!vs.has_x) return h->fail(RESNMTF_ERR_STATE, "set_view missing for an owned view");
-    // --- streaming passes
-    PassArgs& xg = vs.passXG;
-    xg = PassArgs{};
-    xg.A = vs.Xt32; xg.lda = vs.ldxt; xg.ntiles = vs.n_pad / 64; xg.B = vs.G32; xg.ldb = vs.kk_mode == 0 ? vs.KP : 64; xg.P = vs.Pxg;
-    xg.cols_pad = vs.n_pad; xg.rows_pad = vs.m_pad; xg.rows_per_split = vs.rps_xg; xg.nsplit = vs.nsplit_xg;
-    xg.aux[0] = vs.G32; xg.aux[1] = vs.T32; xg.aux[2] = nullptr; xg.naux = 3;     // G^T G, T^T G, colSums(G)
-    xg.Paux = vs.Paux_xg; xg.rows_per_split_aux = vs.rpsaux_xg; xg.nsplit_aux = vs.nsaux_xg; xg.aux_cnt = vs.cnt_xg;
-    xg.ctl = h->ctl;
-    PassArgs& xt = vs.passXtF;
-    xt = PassArgs{};
-    xt.A = vs.X32; xt.lda = vs.ldx; xt.ntiles = vs.m_pad / 64; xt.B = vs.F32; xt.ldb = vs.kk_mode == 0 ? vs.KP : 64; xt.P = vs.Pxtf;
-    xt.cols_pad = vs.m_pad; xt.rows_pad = vs.n_pad; xt.rows_per_split = vs.rps_xtf; xt.nsplit = vs.nsplit_xtf;
-    xt.aux[0] = vs.F32; xt.aux[1] = nullptr; xt.naux = 2;                          // F^T F, colSums(F)
-    xt.Paux = vs.Paux_xtf; xt.rows_per_split_aux = vs.rpsaux_xtf; xt.nsplit_aux = vs.nsaux_xtf; xt.aux_cnt = vs.cnt_xtf;
-    xt.ctl = h->ctl;
+    if (!vs.owned && !vs.f_replica) continue;
     // --- F update (R/update_steps.r:141-165)
     UpdateArgs& f = vs.argF;
     f = UpdateArgs{};
@@ -1091,6 +1107,23 @@ static int build_args(resnmtf_handle* h) {
         c.W = h->views[i].F; c.map = mp.identity ? nullptr : mp.dev; c.weight = wgt; c.n_other = (double)h->views[i].n;
       }
     }
+    if (!vs.owned) continue;       // (an F replica only ever runs PHASE_F)
+    if (!vs.has_x) return h->fail(RESNMTF_ERR_STATE, "set_view missing for an owned view");
+    // --- streaming passes
+    PassArgs& xg = vs.passXG;
+    xg = PassArgs{};
+    xg.A = vs.Xt32; xg.lda = vs.ldxt; xg.ntiles = vs.n_pad / 64; xg.B = vs.G32; xg.ldb = vs.kk_mode == 0 ? vs.KP : 64; xg.P = vs.Pxg;
+    xg.cols_pad = vs.n_pad; xg.rows_pad = vs.m_pad; xg.rows_per_split = vs.rps_xg; xg.nsplit = vs.nsplit_xg;
+    xg.aux[0] = vs.G32; xg.aux[1] = vs.T32; xg.aux[2] = nullptr; xg.naux = 3;     // G^T G, T^T G, colSums(G)
+    xg.Paux = vs.Paux_xg; xg.rows_per_split_aux = vs.rpsaux_xg; xg.nsplit_aux = vs.nsaux_xg; xg.aux_cnt = vs.cnt_xg;
+    xg.ctl = h->ctl;
+    PassArgs& xt = vs.passXtF;
+    xt = PassArgs{};
+    xt.A = vs.X32; xt.lda = vs.ldx; xt.ntiles = vs.m_pad / 64; xt.B = vs.F32; xt.ldb = vs.kk_mode == 0 ? vs.KP : 64; xt.P = vs.Pxtf;
+    xt.cols_pad = vs.m_pad; xt.rows_pad = vs.n_pad; xt.rows_per_split = vs.rps_xtf; xt.nsplit = vs.nsplit_xtf;
+    xt.aux[0] = vs.F32; xt.aux[1] = nullptr; xt.naux = 2;                          // F^T F, colSums(F)
+    xt.Paux = vs.Paux_xtf; xt.rows_per_split_aux = vs.rpsaux_xtf; xt.nsplit_aux = vs.nsaux_xtf; xt.aux_cnt = vs.cnt_xtf;
+    xt.ctl = h->ctl;
     // --- G update (R/update_steps.r:180-207); branch on the WHOLE psi matrix (:190)
     UpdateArgs& g = vs.argG;
     g = UpdateArgs{};
@@ -1175,7 +1208,8 @@ int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep) {
   if (int rc = check_view(h, v)) return rc;
   if (!h->prepared) return h->fail(RESNMTF_ERR_STATE, "resnmtf_prepare has not been called");
   const ViewState& vs = h->views[v];
-  if (!vs.owned) return h->fail(RESNMTF_ERR_STATE, "phase on a view this handle does not own");
+  if (!vs.owned && !(vs.f_replica && phase == RESNMTF_PHASE_F))
+    return h->fail(RESNMTF_ERR_STATE, "phase on a view this handle does not own");
   if (sweep < 0) return h->fail(RESNMTF_ERR_INVALID, "negative sweep index");
   if (sweep >= h->err_cap) return h->fail(RESNMTF_ERR_STATE, "sweep beyond the reserved error buffer (resnmtf_reserve_sweeps)");
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
@@ -1321,6 +1355,9 @@ int resnmtf_factor_device_ptr(resnmtf_handle* h, int v, int which, void** ptr, s
     case RESNMTF_FACTOR_F: *ptr = vs.F; *bytes = (size_t)vs.n * vs.k * sizeof(double); break;
     case RESNMTF_FACTOR_G: *ptr = vs.G; *bytes = (size_t)vs.m * vs.k * sizeof(double); break;
     case RESNMTF_FACTOR_S: *ptr = vs.S; *bytes = (size_t)vs.k * vs.k * sizeof(double); break;
+    case RESNMTF_FACTOR_FBLOCK:
+      if (!vs.fblk) return h->fail(RESNMTF_ERR_STATE, "no F exchange block: create the handle with replicate_f = 1");
+      *ptr = vs.fblk; *bytes = vs.fblk_bytes; break;
     default: return h->fail(RESNMTF_ERR_INVALID, "unknown factor selector");
   }
   return RESNMTF_OK;

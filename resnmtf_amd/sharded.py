@@ -29,6 +29,15 @@ so a rank's two streaming passes (PHASE_G, all of the HBM traffic) overlap the o
 updates and broadcasts of the same sweep; only the F chain itself -- which the reference's
 Gauss-Seidel order makes serial -- stays on the critical path.
 
+Replicated F chain (``replicate_f``, default with the HIP engine).  With phi coupling the F updates
+of a sweep form a chain (F_v' reads F_w' of every coupled w < v), so broadcasting each F_v' puts N
+serial broadcast latencies on the critical path of every sweep.  Instead every rank keeps, for
+every view of a phi-coupled component that spans several ranks, the INPUTS of its F update (the
+X.G slabs, the k x k coefficient matrices, lambda: one contiguous exchange block) and runs that
+update itself -- the same kernel on the same bytes, hence bitwise the same F everywhere.  The block
+of view v is broadcast once per sweep after the owner's PHASE_G(v), off the chain; what remains
+on the critical path of a rank is N short F-update kernels plus its own two passes.
+
 The engine is injected (``engine`` argument) so that the identical driver code runs in the CPU
 tests on a stand-in engine (no streams); in production it is ``resnmtf_amd.engine.Engine``.
 """
@@ -39,10 +48,10 @@ from typing import Callable, Dict, List, Optional, Sequence
 import numpy as np
 
 from . import naming
-from ._lib import FACTOR_F, FACTOR_G, FACTOR_S, PHASE_F, PHASE_G, PHASE_S
+from ._lib import FACTOR_F, FACTOR_FBLOCK, FACTOR_G, FACTOR_S, PHASE_F, PHASE_G, PHASE_S
 from .synth import Problem, planted_view, random_init
 
-_WHICH = {"F": FACTOR_F, "G": FACTOR_G, "S": FACTOR_S}
+_WHICH = {"F": FACTOR_F, "G": FACTOR_G, "S": FACTOR_S, "FBLOCK": FACTOR_FBLOCK}
 
 
 def exchange_plan(n_views: int, owner_of: Sequence[int], phi, xi, psi, row_shared, col_shared) -> List[Dict[str, bool]]:
@@ -66,6 +75,27 @@ def exchange_plan(n_views: int, owner_of: Sequence[int], phi, xi, psi, row_share
                 need["S"] = True
         plan.append(need)
     return plan
+
+
+def replicated_views(n_views: int, owner_of: Sequence[int], phi, row_shared) -> List[bool]:
+    """Views whose F update every rank runs: those in a phi-coupling component (edges: phi != 0 and a
+    shared-row map that is not NA, either direction) whose views live on more than one rank."""
+    phi = np.asarray(phi)
+    parent = list(range(n_views))
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+    for v in range(n_views):
+        for w in range(n_views):
+            if v != w and phi[v, w] != 0 and (row_shared[w].get(v) is not None or row_shared[v].get(w) is not None):
+                parent[find(v)] = find(w)
+    owners: Dict[int, set] = {}
+    for v in range(n_views):
+        owners.setdefault(find(v), set()).add(owner_of[v])
+    return [len(owners[find(v)]) > 1 for v in range(n_views)]
 
 
 class _CudaBlob:
@@ -117,7 +147,7 @@ class HipEngineAdapter:
 
 
 def make_hip_engine(prob: Problem, owned: Sequence[bool], device_index: int, stream: int,
-                    **engine_opts) -> HipEngineAdapter:
+                    replicate_f: bool = False, **engine_opts) -> HipEngineAdapter:
     """Engine for this rank: data only for owned views, factor mirrors for the others, every kernel
     on the given HIP stream -- the torch stream the driver makes current around its broadcasts, so
     that torch.distributed orders them against the kernels.  (The legacy NULL stream must not be
@@ -129,7 +159,7 @@ def make_hip_engine(prob: Problem, owned: Sequence[bool], device_index: int, str
     n_v = len(prob.init_f)
     shapes = prob.extras["shapes"]
     eng = Engine([s[0] for s in shapes], [s[1] for s in shapes], [prob.k] * n_v, owned=list(owned),
-                 device_id=device_index, stream=stream, **engine_opts)
+                 device_id=device_index, stream=stream, replicate_f=replicate_f, **engine_opts)
     for v in range(n_v):
         if owned[v]:
             eng.set_view(v, prob.data[v])
@@ -181,7 +211,7 @@ class ShardedSweep:
 
     def __init__(self, prob: Problem, owner_of: Sequence[int], rank: int, world: int,
                  device_index: int = 0, group=None, engine=None,
-                 engine_factory: Optional[Callable] = None, **engine_opts):
+                 engine_factory: Optional[Callable] = None, replicate_f: Optional[bool] = None, **engine_opts):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -195,6 +225,14 @@ class ShardedSweep:
             prob.extras["shapes"] = [(f.shape[0], g.shape[0]) for f, g in zip(prob.init_f, prob.init_g)]
         row_sh, col_sh = naming.shared_names(prob.row_names), naming.shared_names(prob.col_names)
         self.plan = exchange_plan(self.n_views, self.owner_of, prob.phi, prob.xi, prob.psi, row_sh, col_sh)
+        rep = replicated_views(self.n_views, self.owner_of, prob.phi, row_sh)
+        if replicate_f is None:       # default: on with the HIP engine, off with an injected (stand-in) engine
+            replicate_f = engine is None and engine_factory is None
+        self.replicated = rep if (replicate_f and any(rep)) else [False] * self.n_views
+        if any(self.replicated):      # the F blocks of replicated views travel instead of their F
+            for v in range(self.n_views):
+                if self.replicated[v]:
+                    self.plan[v]["F"] = False
         self._tstream = None      # compute stream (GPU path only)
         self._xstream = None      # exchange stream
         self._ev_f = self._ev_g = self._ev_x = None
@@ -208,7 +246,8 @@ class ShardedSweep:
             torch.cuda.set_device(device_index)
             self._tstream = torch.cuda.Stream(device=device_index)
             self._xstream = self._tstream if self._serial else torch.cuda.Stream(device=device_index)
-            self.engine = make_hip_engine(prob, self.owned, device_index, self._tstream.cuda_stream, **engine_opts)
+            self.engine = make_hip_engine(prob, self.owned, device_index, self._tstream.cuda_stream,
+                                          replicate_f=any(self.replicated), **engine_opts)
         self.sweeps_done = 0
         self._prepared = False
 
@@ -219,9 +258,12 @@ class ShardedSweep:
             self.dist.broadcast(t, src=self.owner_of[v], group=self.group)
             return
         import torch
-        after = self._ev_f if which == "F" else self._ev_g
-        if after is not None and self._xstream is not self._tstream:
-            self._xstream.wait_event(after)
+        # F: after the latest PHASE_F; G / S: after the latest PHASE_G; an F exchange block is complete after
+        # the owner's PHASE_G and must not land while a local PHASE_F still reads the previous one: both
+        if self._xstream is not self._tstream:
+            for after in {"F": (self._ev_f,), "FBLOCK": (self._ev_f, self._ev_g)}.get(which, (self._ev_g,)):
+                if after is not None:
+                    self._xstream.wait_event(after)
         with torch.cuda.stream(self._xstream):         # torch.distributed orders the collective on the current stream
             self.dist.broadcast(t, src=self.owner_of[v], group=self.group)
         if self._xstream is not self._tstream:
@@ -272,18 +314,27 @@ class ShardedSweep:
             self._prepared = True
             self._reserved = max(1024, n_sweeps)
             self._gs_exchanged = any(p["G"] or p["S"] for p in self.plan)
+            if any(self.replicated):      # the run prologue filled the owners' blocks: hand them round once
+                if self._tstream is not None and self._xstream is not self._tstream:
+                    self._ev_g = self._next_event()
+                    self._ev_g.record(self._tstream)
+                for v in range(self.n_views):
+                    if self.replicated[v]:
+                        self._bcast(v, "FBLOCK")
         if self.sweeps_done + n_sweeps > self._reserved:
             raise RuntimeError("reserve more sweeps before the first run() (errors are kept per sweep)")
         for _ in range(n_sweeps):
             t = self.sweeps_done
             for v in range(self.n_views):
                 mine = self.owned[v]
-                if mine:
-                    self._phase(v, (PHASE_F,), t, True)                      # reads the mirrors of coupled F_w
+                if mine or self.replicated[v]:
+                    self._phase(v, (PHASE_F,), t, True)                      # reads the mirrors of coupled F_w (and v's block)
                 if self.plan[v]["F"]:
                     self._bcast(v, "F")
                 if mine:
                     self._phase(v, (PHASE_G, PHASE_S), t, self._gs_exchanged)  # reads G_w / S_w mirrors if exchanged
+                if self.replicated[v]:
+                    self._bcast(v, "FBLOCK")                                 # next sweep's F update inputs, off the chain
                 if self.plan[v]["G"]:
                     self._bcast(v, "G")
                 if self.plan[v]["S"]:

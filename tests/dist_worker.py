@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--rank", type=int, required=True)
     ap.add_argument("--world", type=int, required=True)
     ap.add_argument("--port", type=int, required=True)
-    ap.add_argument("--mode", choices=["cpu", "gpu"], required=True)
+    ap.add_argument("--mode", choices=["cpu", "gpu", "gpu_norep"], required=True)
     ap.add_argument("--sweeps", type=int, default=12)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
@@ -118,14 +118,23 @@ def main():
     if a.mode == "cpu":
         drv = sharded.ShardedSweep(prob, owner_of, a.rank, a.world, engine_factory=lambda p, owned: OracleEngine(p, owned))
     else:
-        drv = sharded.ShardedSweep(prob, owner_of, a.rank, a.world, device_index=0)
+        drv = sharded.ShardedSweep(prob, owner_of, a.rank, a.world, device_index=0, replicate_f=(a.mode == "gpu"))
+        assert any(drv.replicated) == (a.mode == "gpu")
     drv.run(a.sweeps // 2)
     drv.run(a.sweeps - a.sweeps // 2)          # two calls: state carries over
+    mirrors_ok = True
+    if a.mode != "cpu":                          # every rank's copy of every F must be bitwise the owner's
+        import torch
+        drv.engine.synchronize(); torch.cuda.synchronize()
+        mine = [drv.engine.factor_tensor(v, "F").cpu().numpy().tobytes() for v in range(3)]
+        allf = [None] * a.world
+        dist.all_gather_object(allf, mine)
+        mirrors_ok = all(allf[r][v] == allf[owner_of[v]][v] for r in range(a.world) for v in range(3))
     errs = drv.mean_errors()
     res = drv.gather_results(0)
     drv.close()
     if a.rank == 0:
-        out = {"all_error": errs}
+        out = {"all_error": errs, "mirrors_ok": np.array(mirrors_ok)}
         for key, lst in res.items():
             for v, arr in enumerate(lst):
                 out[f"{key}{v}"] = arr

@@ -85,8 +85,13 @@ def test_sharded_schedule_matches_oracle_gloo_cpu(tmp_path):
 
 
 @pytest.mark.gpu
-def test_sharded_hip_two_ranks_one_gpu(tmp_path):
-    got = launch("gpu", tmp_path)
+@pytest.mark.parametrize("mode", ["gpu", "gpu_norep"])
+def test_sharded_hip_two_ranks_one_gpu(tmp_path, mode):
+    """mode "gpu": replicated F chain (every rank runs the F update of every coupled view from the
+    broadcast exchange blocks); "gpu_norep": ordered F broadcasts.  Same results, and every rank's copy of
+    every F is bitwise the owner's."""
+    got = launch(mode, tmp_path)
+    assert bool(got["mirrors_ok"])
     ref = oracle_reference()
     np.testing.assert_allclose(got["all_error"], ref["All_Error"], atol=2e-5, rtol=1e-4)
     for v in range(3):
