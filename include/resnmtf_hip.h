@@ -136,6 +136,24 @@ int resnmtf_set_view(resnmtf_handle* h, int v, const double* x);
 int resnmtf_set_view_raw(resnmtf_handle* h, int v, const double* x_raw, int* was_negative);
 
 /*
+ * View data without a host round trip (the callers of the loop repeat it 36-66 times per apply_resnmtf):
+ *   resnmtf_copy_view     device copy of an uploaded view of another handle on the same GPU (same n x m) --
+ *                         the k sweep (R/main.r:279-290) factorises ONE data set for every k;
+ *   resnmtf_shuffle_view  shuffle_view (R/obtain_bicl.r:11-22): all n m entries of the source view permuted
+ *                         pseudo-randomly on the device (Feistel network with cycle walking, `seed`), then
+ *                         -- normalise != 0 -- non-negativity shift + column normalisation as apply_resnmtf
+ *                         applies to the shuffled data (R/obtain_bicl.r:35 -> R/utils.r:416,422).  R's own
+ *                         sample() stream cannot be reproduced; positive data never yields an empty row or
+ *                         column, so the reference's redraw loop (:14-18) has nothing to do;
+ *   resnmtf_get_view      the device copy back as fp64 column-major (fp32 precision), e.g. for a host-side
+ *                         SVD or for tests.
+ */
+int resnmtf_copy_view(resnmtf_handle* dst, int v, resnmtf_handle* src, int v_src);
+int resnmtf_shuffle_view(resnmtf_handle* dst, int v, resnmtf_handle* src, int v_src, unsigned long long seed,
+                         int normalise);
+int resnmtf_get_view(resnmtf_handle* h, int v, double* x);
+
+/*
  * Initial factors of view v (owned or mirror): F n x k, S k x k, G m x k, column-major.
  * lambda / mu may be NULL: they are then colSums(F) / colSums(G), the reference's
  * explicit-init branch (R/update_steps.r:49-56).

@@ -181,3 +181,76 @@ def run_jobs(jobs: Sequence[Job], device_id: int = 0, group=None, runner: Option
     for part in gathered:
         merged.update(part)
     return [merged[i] for i in range(len(jobs))]
+
+
+# ---------------------------------------------------------------------------------------------
+# the same job kinds with the data resident on the device: one upload, copies / shuffles drawn there
+# ---------------------------------------------------------------------------------------------
+class DeviceData:
+    """The pre-processed views of one data set, uploaded once (``resnmtf_set_view_raw``) and kept for
+    any number of factorisations (``resnmtf_copy_view`` / ``resnmtf_shuffle_view``).  At c2 size an
+    upload costs ~45 ms of PCIe + conversion, 500 sweeps ~23 ms: re-uploading per job would dominate."""
+
+    def __init__(self, data, phi=None, xi=None, psi=None, row_names=None, col_names=None, device_id: int = 0):
+        from . import naming
+        from .engine import Engine
+        self.data_shapes = [np.asarray(d).shape for d in data]
+        n_v = len(data)
+        self.rn, self.cn = naming.give_names([np.asarray(d) for d in data], phi, psi, row_names, col_names)
+        self.phi = naming.init_rest_mats(phi, n_v); self.xi = naming.init_rest_mats(xi, n_v); self.psi = naming.init_rest_mats(psi, n_v)
+        self.device_id = device_id
+        self.base = Engine([s[0] for s in self.data_shapes], [s[1] for s in self.data_shapes], [2] * n_v, device_id=device_id)
+        self.was_negative = [self.base.set_view_raw(v, np.asarray(data[v], dtype=np.float64)) for v in range(n_v)]
+
+    def close(self):
+        self.base.close()
+
+    def factorise(self, k: int, n_iters: Optional[int] = None, seed: int = 0, shuffle_seed: Optional[int] = None,
+                  max_iters: int = 100000, tag: str = "") -> dict:
+        """One factorisation with k biclusters per view: views copied (or, with ``shuffle_seed``, shuffled as
+        ``obtain_shuffled_f`` does -- no restrictions, fresh names) on the device, device SVD init, loop,
+        finalise."""
+        from . import naming
+        from .engine import Engine
+        n_v = len(self.data_shapes)
+        eng = Engine([s[0] for s in self.data_shapes], [s[1] for s in self.data_shapes], [k] * n_v, device_id=self.device_id)
+        try:
+            shuffled = shuffle_seed is not None
+            for v in range(n_v):
+                if shuffled:
+                    eng.shuffle_view_from(v, self.base, v, seed=shuffle_seed * 1000003 + v)
+                else:
+                    eng.copy_view_from(v, self.base, v)
+                eng.init_svd(v, seed=seed + v)
+            if shuffled:
+                eng.set_restrictions(None, None, None)          # R/obtain_bicl.r:35-39: apply_resnmtf without phi/xi/psi
+            else:
+                eng.set_restrictions(self.phi, self.xi, self.psi)
+                rs, cs = naming.shared_names(self.rn), naming.shared_names(self.cn)
+                for v in range(n_v):
+                    for w in range(n_v):
+                        if v != w:
+                            eng.set_shared_rows(v, w, *naming.index_pairs(self.rn[v], self.rn[w], rs[v].get(w)))
+                            eng.set_shared_cols(v, w, *naming.index_pairs(self.cn[v], self.cn[w], cs[v].get(w)))
+            errs = eng.run(n_iters=n_iters, tol=1.0e-6, max_iters=max_iters)
+            fin = [eng.finalise(v) for v in range(n_v)]
+        finally:
+            eng.close()
+        error = float(np.mean(errs[-10:])) if n_iters is None else float(errs[-1])           # R/main.r:126-130
+        return {"output_f": [f[0] for f in fin], "output_s": [f[1] for f in fin], "output_g": [f[2] for f in fin],
+                "row_clusters": [f[3] for f in fin], "col_clusters": [f[4] for f in fin],
+                "Error": error, "All_Error": errs, "tag": tag}
+
+
+def k_sweep_on_device(dev: DeviceData, k_min: int = 3, k_max: int = 8, n_iters=None, seed: int = 0, group=None) -> List[dict]:
+    """The factorisations of the k sweep (``R/main.r:279-290``) from one upload; sharded round-robin over
+    the ranks of an initialised process group (every rank holds its own ``DeviceData``)."""
+    ks = list(range(k_min, k_max + 1))
+    return run_jobs(ks, group=group, runner=lambda k: dev.factorise(k, n_iters, seed + k, tag=f"k={k}"))
+
+
+def shuffles_on_device(dev: DeviceData, n_clusts: int, num_repeats: int = 5, n_iters=None, seed: int = 0, group=None) -> List[dict]:
+    """``obtain_shuffled_f`` (``R/obtain_bicl.r:31-42``) with the shuffles drawn on the device."""
+    reps = list(range(num_repeats))
+    return run_jobs(reps, group=group,
+                    runner=lambda r: dev.factorise(n_clusts, n_iters, seed + 1000 + r, shuffle_seed=seed * 7919 + r + 1, tag=f"shuffle={r}"))

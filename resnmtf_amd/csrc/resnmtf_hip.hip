@@ -657,9 +657,12 @@ int resnmtf_destroy(resnmtf_handle* h) {
 namespace {
 // raw = false: x is already non-negative and column-normalised.  raw = true: make_non_neg_inner +
 // matrix_normalisation (R/utils.r:20-27, 86-88) run on the device, fused into the conversion.
-int upload_view(resnmtf_handle* h, int v, const double* x, bool raw, int* was_negative) {
+// Source of the staging image: the host matrix x, or (x == NULL) a pseudo-random permutation of the
+// entries of another view's device copy (shuffle_src, see resnmtf_shuffle_view).
+struct ShuffleSrc { const float* X32; int ldx; unsigned long long seed; };
+int upload_view(resnmtf_handle* h, int v, const double* x, bool raw, int* was_negative, const ShuffleSrc* shuffle_src = nullptr) {
   if (int rc = check_view(h, v)) return rc;
-  if (!x) return h->fail(RESNMTF_ERR_INVALID, "x is NULL");
+  if (!x && !shuffle_src) return h->fail(RESNMTF_ERR_INVALID, "x is NULL");
   ViewState& vs = h->views[v];
   if (!vs.owned) return h->fail(RESNMTF_ERR_STATE, "set_view on a view this handle does not own");
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
@@ -678,7 +681,12 @@ int upload_view(resnmtf_handle* h, int v, const double* x, bool raw, int* was_ne
   double* colsum = raw ? colstat + vs.m : nullptr;
   int* neg = raw ? reinterpret_cast<int*>(colstat + 2 * (size_t)vs.m) : nullptr;
   int neg_host = 0;
-  e = hipMemcpyAsync(staging, x, count * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (x) e = hipMemcpyAsync(staging, x, count * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  else {
+    hipLaunchKernelGGL(shuffle_gather_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream, shuffle_src->X32,
+                       shuffle_src->ldx, vs.n, vs.m, shuffle_src->seed, staging);
+    e = hipGetLastError();
+  }
   if (e == hipSuccess) e = hipMemsetAsync(vs.X32, 0, (size_t)vs.n_pad * vs.ldx * sizeof(float), h->stream);
   if (e == hipSuccess) e = hipMemsetAsync(vs.Xt32, 0, (size_t)vs.m_pad * vs.ldxt * sizeof(float), h->stream);
   if (e == hipSuccess && raw) e = hipMemsetAsync(neg, 0, sizeof(double), h->stream);
@@ -704,6 +712,59 @@ int upload_view(resnmtf_handle* h, int v, const double* x, bool raw, int* was_ne
 int resnmtf_set_view(resnmtf_handle* h, int v, const double* x) { return upload_view(h, v, x, false, nullptr); }
 int resnmtf_set_view_raw(resnmtf_handle* h, int v, const double* x_raw, int* was_negative) {
   return upload_view(h, v, x_raw, true, was_negative);
+}
+
+// ---- view data without a host round trip (the k sweep re-uses one upload, the shuffles of
+// spurious-bicluster removal are drawn on the device)
+static int check_view_pair(resnmtf_handle* dst, int v, resnmtf_handle* src, int v_src) {
+  if (int rc = check_view(dst, v)) return rc;
+  if (!src || v_src < 0 || v_src >= src->V) return dst->fail(RESNMTF_ERR_INVALID, "bad source handle / view");
+  const ViewState& a = dst->views[v];
+  const ViewState& b = src->views[v_src];
+  if (!a.owned || !b.owned || !b.has_x) return dst->fail(RESNMTF_ERR_STATE, "both views must be owned and the source uploaded");
+  if (a.n != b.n || a.m != b.m) return dst->fail(RESNMTF_ERR_INVALID, "views differ in shape");
+  if (dst->opt.device_id != src->opt.device_id) return dst->fail(RESNMTF_ERR_INVALID, "handles live on different devices");
+  return RESNMTF_OK;
+}
+
+int resnmtf_copy_view(resnmtf_handle* dst, int v, resnmtf_handle* src, int v_src) {
+  if (int rc = check_view_pair(dst, v, src, v_src)) return rc;
+  ViewState& a = dst->views[v];
+  const ViewState& b = src->views[v_src];
+  HIP_TRY(dst, hipSetDevice(dst->opt.device_id));
+  HIP_TRY(dst, hipStreamSynchronize(src->stream));
+  if (int rc = sync_both(dst)) return rc;
+  // same shape and options decide the same pitches; guard anyway
+  if (a.ldx != b.ldx || a.ldxt != b.ldxt) return dst->fail(RESNMTF_ERR_INVALID, "views differ in device layout (no_pitch_pad)");
+  HIP_TRY(dst, hipMemcpyAsync(a.X32, b.X32, (size_t)a.n_pad * a.ldx * sizeof(float), hipMemcpyDeviceToDevice, dst->stream));
+  HIP_TRY(dst, hipMemcpyAsync(a.Xt32, b.Xt32, (size_t)a.m_pad * a.ldxt * sizeof(float), hipMemcpyDeviceToDevice, dst->stream));
+  HIP_TRY(dst, hipMemcpyAsync(a.xnorm2, b.xnorm2, sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+  HIP_TRY(dst, hipStreamSynchronize(dst->stream));
+  a.has_x = true;
+  return RESNMTF_OK;
+}
+
+int resnmtf_shuffle_view(resnmtf_handle* dst, int v, resnmtf_handle* src, int v_src, unsigned long long seed, int normalise) {
+  if (int rc = check_view_pair(dst, v, src, v_src)) return rc;
+  const ViewState& b = src->views[v_src];
+  HIP_TRY(dst, hipSetDevice(dst->opt.device_id));
+  HIP_TRY(dst, hipStreamSynchronize(src->stream));
+  const ShuffleSrc sh{b.X32, b.ldx, seed};
+  return upload_view(dst, v, nullptr, normalise != 0, nullptr, &sh);
+}
+
+int resnmtf_get_view(resnmtf_handle* h, int v, double* x) {
+  if (int rc = check_view(h, v)) return rc;
+  if (!x) return h->fail(RESNMTF_ERR_INVALID, "x is NULL");
+  const ViewState& vs = h->views[v];
+  if (!vs.owned || !vs.has_x) return h->fail(RESNMTF_ERR_STATE, "no data on this handle for the view");
+  HIP_TRY(h, hipSetDevice(h->opt.device_id));
+  if (int rc = sync_both(h)) return rc;
+  std::vector<float> t((size_t)vs.m * vs.ldxt);          // Xt32 rows = columns of X: already R's column-major order
+  HIP_TRY(h, hipMemcpy(t.data(), vs.Xt32, t.size() * sizeof(float), hipMemcpyDeviceToHost));
+  for (int c = 0; c < vs.m; ++c)
+    for (int r = 0; r < vs.n; ++r) x[(size_t)c * vs.n + r] = (double)t[(size_t)c * vs.ldxt + r];
+  return RESNMTF_OK;
 }
 
 int resnmtf_set_factors(resnmtf_handle* h, int v, const double* F, const double* S, const double* G,

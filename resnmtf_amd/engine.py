@@ -114,6 +114,20 @@ class Engine:
         self._check(self._lib.resnmtf_set_view_raw(self._h, v, _dp(x), C.byref(neg)))
         return bool(neg.value)
 
+    def copy_view_from(self, v: int, other: "Engine", v_src: int = 0):
+        """Device copy of a view another engine (same GPU, same shape) has uploaded."""
+        self._check(self._lib.resnmtf_copy_view(self._h, v, other._h, v_src))
+
+    def shuffle_view_from(self, v: int, other: "Engine", v_src: int = 0, seed: int = 0, normalise: bool = True):
+        """``shuffle_view`` (``R/obtain_bicl.r:11-22``) of another engine's view, drawn on the device."""
+        self._check(self._lib.resnmtf_shuffle_view(self._h, v, other._h, v_src, int(seed), 1 if normalise else 0))
+
+    def get_view(self, v: int) -> np.ndarray:
+        """The device copy of the view's data (fp32 precision) as an fp64 matrix."""
+        x = np.zeros((self.n_rows[v], self.n_cols[v]), order="F")
+        self._check(self._lib.resnmtf_get_view(self._h, v, _dp(x)))
+        return x
+
     def init_svd(self, v: int, seed: int = 0, sigma: float = 0.05, n_power: int = 0) -> np.ndarray:
         """``init_mats_inner`` (``R/update_steps.r:78-125``) on the device for view ``v`` (randomized
         top-k SVD on the streaming-pass kernels); returns the k leading singular values."""

@@ -91,3 +91,57 @@ def test_batched_factorisations_on_gpu():
     for r in stab:
         assert r["output_f"][0].shape == (162, 3) and len(r["extras"]["row_samples"][0]) == 162
         assert sorted(r["row_clusters"][0].sum(0)) == sorted(rc[r["extras"]["row_samples"][0]].sum(0))
+
+
+@pytest.mark.gpu
+def test_device_resident_views_copy_shuffle_readback():
+    """resnmtf_copy_view / resnmtf_shuffle_view / resnmtf_get_view: the copy factorises bitwise like a
+    fresh upload; the shuffle is a permutation of the entries (normalise = 0), seeded, and with
+    normalise = 1 column-normalised like the reference's shuffled input to apply_resnmtf."""
+    from resnmtf_amd import synth
+    from resnmtf_amd.engine import Engine
+    prob = synth.make_problem([(500, 260)], 5)
+    x = prob.data[0]
+    base = Engine([500], [260], [5]); base.set_view(0, x)
+    np.testing.assert_allclose(base.get_view(0), x, rtol=1e-6, atol=0)                    # fp32 device copy
+    outs = []
+    for mode in ("upload", "copy"):
+        e = Engine([500], [260], [5])
+        if mode == "upload":
+            e.set_view(0, x)
+        else:
+            e.copy_view_from(0, base, 0)
+        e.set_restrictions(); e.set_factors(0, prob.init_f[0], prob.init_s[0], prob.init_g[0])
+        outs.append((e.run(25), e.finalise(0)[0])); e.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    e = Engine([500], [260], [5])
+    e.shuffle_view_from(0, base, 0, seed=11, normalise=False)
+    s1 = e.get_view(0)
+    np.testing.assert_array_equal(np.sort(s1.ravel()), np.sort(base.get_view(0).ravel()))  # a permutation of the entries
+    assert np.mean(s1 == base.get_view(0)) < 0.05                                          # ... that moves them
+    e.shuffle_view_from(0, base, 0, seed=11, normalise=False)
+    assert np.array_equal(e.get_view(0), s1)                                               # seeded
+    e.shuffle_view_from(0, base, 0, seed=12, normalise=False)
+    assert not np.array_equal(e.get_view(0), s1)
+    e.shuffle_view_from(0, base, 0, seed=11, normalise=True)
+    np.testing.assert_allclose(e.get_view(0).sum(0), 1.0, rtol=1e-5)
+    e.close(); base.close()
+
+
+@pytest.mark.gpu
+def test_k_sweep_and_shuffles_from_one_upload():
+    rng = np.random.default_rng(5)
+    rc = np.kron(np.eye(3), np.ones((60, 1)))
+    x = [rc @ (10.0 * np.eye(3)) @ rc.T + 0.1 * np.abs(rng.normal(size=(180, 180)))]
+    dev = batched.DeviceData(x)
+    sweep = batched.k_sweep_on_device(dev, 2, 4, n_iters=200)
+    host = batched.run_jobs(batched.k_sweep_jobs(x, 2, 4, n_iters=200))
+    for a, b in zip(sweep, host):                                   # same seeds, same device init: same factorisations
+        assert abs(a["Error"] - b["Error"]) < 1e-6 * max(1.0, b["Error"]) + 1e-7
+    assert sorted(sweep[1]["row_clusters"][0].sum(0)) == [60.0, 60.0, 60.0]
+    shuf = batched.shuffles_on_device(dev, 3, num_repeats=3, n_iters=200)
+    for r in shuf:
+        np.testing.assert_allclose(r["output_f"][0].sum(0), 1.0, atol=1e-12)
+        assert r["Error"] > 10 * sweep[1]["Error"]
+    assert not np.array_equal(shuf[0]["output_f"][0], shuf[1]["output_f"][0])
+    dev.close()
