@@ -28,15 +28,23 @@ res_nmtf_inner_hip <- function(
     init_f = NULL, init_s = NULL, init_g = NULL,
     k_vec = NULL, phi = NULL, xi = NULL, psi = NULL,
     n_iters = NULL, num_repeats = 5, spurious = TRUE, distance = "euclidean",
-    no_clusts = FALSE, max_iters = 100000L) {
+    no_clusts = FALSE, max_iters = 100000L, device_init = TRUE, seed = 0L) {
   n_v <- length(data)
-  # initial factors exactly as the reference builds them (SVD + noise, or the explicit branch)
-  initial_mats <- init_mats(data, n_v, k_vec, init_f, init_g, init_s)        # R/update_steps.r:36-66
+  # initial factors: explicit ones as given (R/update_steps.r:49-61); otherwise init_mats_inner
+  # (R/update_steps.r:78-125) either on the device (resnmtf_init_svd: randomized top-k SVD, milliseconds)
+  # or, device_init = FALSE, exactly as the reference builds them (full svd() in R)
+  explicit <- !(is.null(init_f) || is.null(init_g) || is.null(init_s))
+  if (explicit || !device_init) {
+    initial_mats <- init_mats(data, n_v, k_vec, init_f, init_g, init_s)      # R/update_steps.r:36-66
+    f0 <- initial_mats$current_f; s0 <- initial_mats$current_s; g0 <- initial_mats$current_g
+  } else {
+    f0 <- NULL; s0 <- NULL; g0 <- NULL
+  }
   row_maps <- name_maps(row_indices, lapply(data, rownames))
   col_maps <- name_maps(column_indices, lapply(data, colnames))
-  res <- .Call("resnmtf_hip_inner", data, initial_mats$current_f, initial_mats$current_s,
-               initial_mats$current_g, phi, xi, psi, row_maps, col_maps,
-               as.integer(ifelse(is.null(n_iters), 0L, n_iters)), as.integer(max_iters))
+  res <- .Call("resnmtf_hip_inner", data, f0, s0, g0, phi, xi, psi, row_maps, col_maps,
+               as.integer(ifelse(is.null(n_iters), 0L, n_iters)), as.integer(max_iters),
+               as.integer(k_vec), as.integer(seed))
   for (v in seq_len(n_v)) {                                                  # R/update_steps.r:57-60
     rownames(res$output_f[[v]]) <- rownames(data[[v]])
     rownames(res$output_g[[v]]) <- colnames(data[[v]])

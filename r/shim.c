@@ -51,22 +51,31 @@ static void set_maps(resnmtf_handle* h, SEXP maps, int n_v, int rows) {
   }
 }
 
+/* init_f / init_s / init_g may be R_NilValue: the initial factors then come from the device
+ * (resnmtf_init_svd = init_mats_inner, R/update_steps.r:78-125; k from k_vec_, noise seed from seed_). */
 SEXP resnmtf_hip_inner(SEXP data, SEXP init_f, SEXP init_s, SEXP init_g, SEXP phi, SEXP xi, SEXP psi,
-                       SEXP row_maps, SEXP col_maps, SEXP n_iters_, SEXP max_iters_) {
+                       SEXP row_maps, SEXP col_maps, SEXP n_iters_, SEXP max_iters_, SEXP k_vec_, SEXP seed_) {
   const int n_v = length(data);
+  const int device_init = isNull(init_f) || isNull(init_s) || isNull(init_g);
   int* nr = (int*)R_alloc(n_v, sizeof(int));
   int* nc = (int*)R_alloc(n_v, sizeof(int));
   int* kk = (int*)R_alloc(n_v, sizeof(int));
   for (int v = 0; v < n_v; ++v) {
-    nr[v] = nrows(VECTOR_ELT(data, v)); nc[v] = ncols(VECTOR_ELT(data, v)); kk[v] = ncols(VECTOR_ELT(init_f, v));
+    nr[v] = nrows(VECTOR_ELT(data, v)); nc[v] = ncols(VECTOR_ELT(data, v));
+    kk[v] = device_init ? INTEGER(k_vec_)[v] : ncols(VECTOR_ELT(init_f, v));
   }
   resnmtf_handle* h = NULL;
   if (resnmtf_create(n_v, nr, nc, kk, NULL, NULL, &h)) fail(NULL, "resnmtf_create");
   for (int v = 0; v < n_v; ++v) {
     if (resnmtf_set_view(h, v, REAL(VECTOR_ELT(data, v)))) fail(h, "resnmtf_set_view");
-    /* lambda = mu = NULL: colSums, the explicit-init branch of R/update_steps.r:55-56 */
-    if (resnmtf_set_factors(h, v, REAL(VECTOR_ELT(init_f, v)), REAL(VECTOR_ELT(init_s, v)),
-                            REAL(VECTOR_ELT(init_g, v)), NULL, NULL)) fail(h, "resnmtf_set_factors");
+    if (device_init) {
+      if (resnmtf_init_svd(h, v, (unsigned long long)asInteger(seed_) + (unsigned long long)v, 0.05, 0, NULL))
+        fail(h, "resnmtf_init_svd");
+    } else if (resnmtf_set_factors(h, v, REAL(VECTOR_ELT(init_f, v)), REAL(VECTOR_ELT(init_s, v)),
+                                   REAL(VECTOR_ELT(init_g, v)), NULL, NULL)) {
+      /* lambda = mu = NULL: colSums, the explicit-init branch of R/update_steps.r:55-56 */
+      fail(h, "resnmtf_set_factors");
+    }
   }
   if (resnmtf_set_restrictions(h, REAL(phi), REAL(xi), REAL(psi))) fail(h, "resnmtf_set_restrictions");
   if (n_v > 1) { set_maps(h, row_maps, n_v, 1); set_maps(h, col_maps, n_v, 0); }
