@@ -145,11 +145,18 @@ def run_sharded(args) -> dict:
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # rehearsal on a one-GPU box: RESNMTF_BENCH_DEVICE pins every rank to one device and
+    # RESNMTF_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU); never set by the driver
+    if os.environ.get("RESNMTF_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["RESNMTF_BENCH_DEVICE"])
+    backend = os.environ.get("RESNMTF_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
-    dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                            device_id=torch.device("cuda", local_rank))
+    if backend == "nccl":
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     n_views = world
     n, m, k = 10000, 2000, 16
     # every rank builds only the view it owns (same seeds as synth.make_problem) + all initial factors
@@ -164,7 +171,7 @@ def run_sharded(args) -> dict:
     drv.run(args.steps)
     dist.barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     errs = drv.mean_errors()
