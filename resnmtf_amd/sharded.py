@@ -264,8 +264,9 @@ class ShardedSweep:
             for after in {"F": (self._ev_f,), "FBLOCK": (self._ev_f, self._ev_g)}.get(which, (self._ev_g,)):
                 if after is not None:
                     self._xstream.wait_event(after)
-        with torch.cuda.stream(self._xstream):         # torch.distributed orders the collective on the current stream
-            self.dist.broadcast(t, src=self.owner_of[v], group=self.group)
+        # torch.distributed orders the collective on the CURRENT stream: run() has made the exchange stream
+        # current for the whole call (the engine enqueues on its own stream handle regardless)
+        self.dist.broadcast(t, src=self.owner_of[v], group=self.group)
         if self._xstream is not self._tstream:
             self._ev_x = self._next_event()
             self._ev_x.record(self._xstream)
@@ -302,7 +303,7 @@ class ShardedSweep:
             return
         if self._tstream is not None:
             import torch
-            with torch.cuda.stream(self._tstream):
+            with torch.cuda.stream(self._xstream):      # one context switch per call, not one per broadcast
                 self._run(n_sweeps)
             return
         self._run(n_sweeps)

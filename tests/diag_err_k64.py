@@ -3,7 +3,7 @@
 rel-Frobenius distance of F / G / S to the oracle after 30 sweeps.  LIB=path selects the library."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))  # lives in tests/: it calls the oracle
 import numpy as np
 from resnmtf_amd import _lib, synth
 if os.environ.get("LIB"):
