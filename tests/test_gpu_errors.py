@@ -1,0 +1,70 @@
+"""Error behaviour of the C-ABI on a real device: misuse is refused with a code and a message, never
+a crash or a silent wrong answer (return conventions of include/resnmtf_hip.h)."""
+import numpy as np
+import pytest
+
+from resnmtf_amd import _lib, synth
+from resnmtf_amd.engine import Engine, ResnmtfError
+
+pytestmark = pytest.mark.gpu
+
+
+def test_create_rejects_bad_descriptions():
+    for args in (([10], [8], [65]), ([10], [8], [0]), ([10], [8], [9]), ([5] * 18, [5] * 18, [2] * 18)):
+        with pytest.raises(ResnmtfError) as ei:
+            Engine(*args)
+        assert ei.value.args[0] == _lib.ERR_INVALID if hasattr(_lib, "ERR_INVALID") else True
+
+
+def test_call_order_is_enforced():
+    prob = synth.make_problem([(60, 40)], 3)
+    e = Engine([60], [40], [3])
+    with pytest.raises(ResnmtfError, match="set_factors"):
+        e.run(2)                                           # no factors yet
+    e.set_factors(0, prob.init_f[0], prob.init_s[0], prob.init_g[0])
+    with pytest.raises(ResnmtfError, match="set_view"):
+        e.run(2)                                           # no data yet
+    with pytest.raises(ResnmtfError, match="set_view"):
+        e.init_svd(0)                                      # the SVD init needs the data
+    e.set_view(0, prob.data[0]); e.set_restrictions()
+    assert len(e.run(3)) == 3
+    with pytest.raises(ResnmtfError):
+        e.set_shared_rows(0, 0, np.zeros(1, np.int32), np.zeros(1, np.int32))      # a view with itself
+    with pytest.raises(ResnmtfError, match="out of range"):
+        e.phase(3, _lib.PHASE_F, 0)                        # view index out of range (checked by the library)
+    e.close()
+
+
+def test_ownership_is_enforced():
+    prob = synth.make_problem([(60, 40), (60, 30)], 3, phi=1.0)
+    e = Engine([60, 60], [40, 30], [3, 3], owned=[True, False])
+    with pytest.raises(ResnmtfError, match="own"):
+        e.set_view(1, prob.data[1])                        # not this handle's view
+    e.set_view(0, prob.data[0])
+    for v in range(2):
+        e.set_factors(v, prob.init_f[v], prob.init_s[v], prob.init_g[v])
+    e.set_restrictions(prob.phi, prob.xi, prob.psi)
+    with pytest.raises(ResnmtfError, match="owns every view"):
+        e.run(2)                                           # resnmtf_run needs all views; sharded use goes through phases
+    e.reserve_sweeps(8); e.prepare()
+    with pytest.raises(ResnmtfError, match="own"):
+        e.phase(1, _lib.PHASE_F, 0)                        # no replicate_f: F of view 1 is not computed here
+    with pytest.raises(ResnmtfError):
+        e.factor_device_ptr(0, _lib.FACTOR_FBLOCK)         # exchange blocks exist only with replicate_f
+    e.phase(0, _lib.PHASE_F, 0); e.phase(0, _lib.PHASE_G, 0); e.synchronize()
+    assert np.isfinite(e.view_errors(0, 0, 1)).all()
+    e.close()
+
+
+def test_device_copies_check_shapes():
+    a = Engine([50], [30], [3]); b = Engine([50], [31], [3]); c = Engine([50], [30], [4])
+    x = synth.planted_view(50, 30, 3, 1)
+    with pytest.raises(ResnmtfError, match="uploaded"):
+        c.copy_view_from(0, a, 0)                          # source has no data yet
+    a.set_view(0, x)
+    with pytest.raises(ResnmtfError, match="shape"):
+        b.copy_view_from(0, a, 0)
+    c.copy_view_from(0, a, 0)                              # a different k is fine: only the data travels
+    np.testing.assert_array_equal(c.get_view(0), a.get_view(0))
+    for e in (a, b, c):
+        e.close()
