@@ -235,7 +235,8 @@ class ShardedSweep:
                     self.plan[v]["F"] = False
         self._tstream = None      # compute stream (GPU path only)
         self._xstream = None      # exchange stream
-        self._ev_f = self._ev_g = self._ev_x = None
+        self._ev_f = self._ev_g = None
+        self._ev_recv: Dict[tuple, object] = {}      # (view, factor) -> event after its latest broadcast
         self._serial = bool(engine_opts.pop("serial_exchange", False))   # one-stream fallback (diagnostic)
         if engine is not None:
             self.engine = engine
@@ -268,8 +269,10 @@ class ShardedSweep:
         # current for the whole call (the engine enqueues on its own stream handle regardless)
         self.dist.broadcast(t, src=self.owner_of[v], group=self.group)
         if self._xstream is not self._tstream:
-            self._ev_x = self._next_event()
-            self._ev_x.record(self._xstream)
+            ev = self._ev_recv.get((v, which))           # one dedicated event per (view, factor), re-recorded
+            if ev is None:
+                ev = self._ev_recv[(v, which)] = torch.cuda.Event()
+            ev.record(self._xstream)
 
     def _next_event(self):
         """Events are recycled round-robin: a wait captures the record that precedes it, so an event
@@ -285,8 +288,16 @@ class ShardedSweep:
     def _phase(self, v: int, phases, sweep: int, reads_mirrors: bool):
         """Enqueue phases of an owned view on the compute stream, after the broadcasts they read."""
         two = self._tstream is not None and self._xstream is not self._tstream
-        if two and reads_mirrors and self._ev_x is not None:
-            self._tstream.wait_event(self._ev_x)
+        if two and reads_mirrors:
+            # only what the phase reads: PHASE_F(v) its own exchange block and the broadcast F mirrors (the
+            # replicated ones are computed on this very stream); PHASE_G / PHASE_S the G and S mirrors --
+            # NOT the latest broadcast of any kind, which would turn every sweep into a barrier
+            if phases[0] == PHASE_F:
+                waits = [ev for (w, which), ev in self._ev_recv.items() if which == "F" or (which == "FBLOCK" and w == v)]
+            else:
+                waits = [ev for (w, which), ev in self._ev_recv.items() if which in ("G", "S")]
+            for ev in waits:
+                self._tstream.wait_event(ev)
         for ph in phases:
             self.engine.phase(v, ph, sweep)
         if two:
