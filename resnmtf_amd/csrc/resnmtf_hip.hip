@@ -151,8 +151,8 @@ void to_col_major(const std::vector<double>& src, int rows, int cols, double* ds
 }
 
 size_t update_smem_bytes(int KP) {
-  const int RG = UPDATE_THREADS / KP;
-  return sizeof(double) * ((size_t)2 * KP * KP + 3 * (size_t)RG * KP + 2 * UPDATE_THREADS);
+  const int UT = update_threads(KP), RG = UT / KP;      // (padded pitches of the fp64-MFMA form included)
+  return sizeof(double) * ((size_t)2 * KP * (KP + 16) + 2 * (size_t)RG * (KP + 2) + (size_t)RG * KP + 2 * UT + 2 * 16 * (size_t)(KP + 16));
 }
 size_t kk_smem_bytes(int KP, int NW) { return sizeof(double) * ((size_t)4 * KP * KP + 3 * 64 * (size_t)NW); }
 size_t pass_smem_bytes(int KP, int NW) {
@@ -305,8 +305,8 @@ void launch_update(resnmtf_handle* h, const ViewState& v, int kind, bool check_d
   const bool emit = v.kk_mode == 0;
   // coupling-count bucket of the kernel instantiation: 0 = unrestricted form, else room for 4, 8 or 16 coupled views
 #define LAUNCH_UPD_K(KPV, G_, C_)                                                                                      \
-  if (emit) hipLaunchKernelGGL((factor_update_kernel<KPV, G_, C_, true>), dim3(nblk), dim3(UPDATE_THREADS), smem, h->stream, a); \
-  else hipLaunchKernelGGL((factor_update_kernel<KPV, G_, C_, false>), dim3(nblk), dim3(UPDATE_THREADS), smem, h->stream, a)
+  if (emit) hipLaunchKernelGGL((factor_update_kernel<KPV, G_, C_, true>), dim3(nblk), dim3(update_threads(KPV)), smem, h->stream, a); \
+  else hipLaunchKernelGGL((factor_update_kernel<KPV, G_, C_, false>), dim3(nblk), dim3(update_threads(KPV)), smem, h->stream, a)
 #define LAUNCH_UPD_C(KPV, G_)                                               \
   if (!a.restricted) { LAUNCH_UPD_K(KPV, G_, 0); }                          \
   else if (a.n_couple <= 4) { LAUNCH_UPD_K(KPV, G_, 4); }                   \
@@ -571,7 +571,7 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
               &vs.nsplit_xg, &vs.rps_xg, &vs.nw_xg);
     size_pass(vs.NT, vs.m_pad / 64, vs.n_pad, slots_xtf, max_pass_waves(vs.NT), o.pass_waves, o.pass_splits_xtf,
               &vs.nsplit_xtf, &vs.rps_xtf, &vs.nw_xtf);
-    const int RG = UPDATE_THREADS / vs.KP;
+    const int RG = update_threads(vs.KP) / vs.KP;
     // update workgroups: mode A ~160 (few partials for the k x k job, two prefetched row groups each
     // at c2 -- tools/tune_c2.py); mode B one row group per workgroup up to 1024 workgroups (a single
     // memory round trip each)
