@@ -152,7 +152,8 @@ void to_col_major(const std::vector<double>& src, int rows, int cols, double* ds
 
 size_t update_smem_bytes(int KP) {
   const int UT = update_threads(KP), RG = UT / KP;      // (padded pitches of the fp64-MFMA form included)
-  return sizeof(double) * ((size_t)2 * KP * (KP + 16) + 2 * (size_t)RG * (KP + 2) + (size_t)RG * KP + 2 * UT + 2 * 16 * (size_t)(KP + 16));
+  const int P16 = (KP % 32 == 0) ? KP + 16 : KP + 32;
+  return sizeof(double) * ((size_t)2 * KP * P16 + 2 * (size_t)RG * (KP + 2) + (size_t)RG * KP + 2 * UT + 2 * (size_t)RG * P16);
 }
 size_t kk_smem_bytes(int KP, int NW) { return sizeof(double) * ((size_t)4 * KP * KP + 3 * 64 * (size_t)NW); }
 size_t pass_smem_bytes(int KP, int NW) {
