@@ -145,12 +145,16 @@ int resnmtf_set_view_raw(resnmtf_handle* h, int v, const double* x_raw, int* was
  *                         applies to the shuffled data (R/obtain_bicl.r:35 -> R/utils.r:416,422).  R's own
  *                         sample() stream cannot be reproduced; positive data never yields an empty row or
  *                         column, so the reference's redraw loop (:14-18) has nothing to do;
+ *   resnmtf_subsample_view  the sub-sample X[rows, cols] of stability_repeat (R/stability_analysis.r:230-249; dst's
+ *                         shape = the index counts; 0-based indices into the source view), NOT re-normalised,
+ *                         exactly as the reference factorises it;
  *   resnmtf_get_view      the device copy back as fp64 column-major (fp32 precision), e.g. for a host-side
  *                         SVD or for tests.
  */
 int resnmtf_copy_view(resnmtf_handle* dst, int v, resnmtf_handle* src, int v_src);
 int resnmtf_shuffle_view(resnmtf_handle* dst, int v, resnmtf_handle* src, int v_src, unsigned long long seed,
                          int normalise);
+int resnmtf_subsample_view(resnmtf_handle* dst, int v, resnmtf_handle* src, int v_src, const int* rows, const int* cols);
 int resnmtf_get_view(resnmtf_handle* h, int v, double* x);
 
 /*

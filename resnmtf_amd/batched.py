@@ -206,19 +206,27 @@ class DeviceData:
         self.base.close()
 
     def factorise(self, k: int, n_iters: Optional[int] = None, seed: int = 0, shuffle_seed: Optional[int] = None,
-                  max_iters: int = 100000, tag: str = "") -> dict:
-        """One factorisation with k biclusters per view: views copied (or, with ``shuffle_seed``, shuffled as
-        ``obtain_shuffled_f`` does -- no restrictions, fresh names) on the device, device SVD init, loop,
-        finalise."""
+                  max_iters: int = 100000, tag: str = "", samples=None) -> dict:
+        """One factorisation with k biclusters per view: views copied -- or, with ``shuffle_seed``, shuffled as
+        ``obtain_shuffled_f`` does (no restrictions, fresh names), or, with ``samples = (row_samples,
+        col_samples)``, sub-sampled as ``stability_repeat`` does (not re-normalised, names carried over) --
+        on the device, device SVD init, loop, finalise."""
         from . import naming
         from .engine import Engine
         n_v = len(self.data_shapes)
-        eng = Engine([s[0] for s in self.data_shapes], [s[1] for s in self.data_shapes], [k] * n_v, device_id=self.device_id)
+        shapes = self.data_shapes if samples is None else [(len(samples[0][v]), len(samples[1][v])) for v in range(n_v)]
+        rn, cn = self.rn, self.cn
+        if samples is not None:
+            rn = [[self.rn[v][t] for t in samples[0][v]] for v in range(n_v)]
+            cn = [[self.cn[v][t] for t in samples[1][v]] for v in range(n_v)]
+        eng = Engine([s[0] for s in shapes], [s[1] for s in shapes], [k] * n_v, device_id=self.device_id)
         try:
             shuffled = shuffle_seed is not None
             for v in range(n_v):
                 if shuffled:
                     eng.shuffle_view_from(v, self.base, v, seed=shuffle_seed * 1000003 + v)
+                elif samples is not None:
+                    eng.subsample_view_from(v, self.base, v, samples[0][v], samples[1][v])
                 else:
                     eng.copy_view_from(v, self.base, v)
                 eng.init_svd(v, seed=seed + v)
@@ -226,12 +234,12 @@ class DeviceData:
                 eng.set_restrictions(None, None, None)          # R/obtain_bicl.r:35-39: apply_resnmtf without phi/xi/psi
             else:
                 eng.set_restrictions(self.phi, self.xi, self.psi)
-                rs, cs = naming.shared_names(self.rn), naming.shared_names(self.cn)
+                rs, cs = naming.shared_names(rn), naming.shared_names(cn)
                 for v in range(n_v):
                     for w in range(n_v):
                         if v != w:
-                            eng.set_shared_rows(v, w, *naming.index_pairs(self.rn[v], self.rn[w], rs[v].get(w)))
-                            eng.set_shared_cols(v, w, *naming.index_pairs(self.cn[v], self.cn[w], cs[v].get(w)))
+                            eng.set_shared_rows(v, w, *naming.index_pairs(rn[v], rn[w], rs[v].get(w)))
+                            eng.set_shared_cols(v, w, *naming.index_pairs(cn[v], cn[w], cs[v].get(w)))
             errs = eng.run(n_iters=n_iters, tol=1.0e-6, max_iters=max_iters)
             fin = [eng.finalise(v) for v in range(n_v)]
         finally:
@@ -239,7 +247,8 @@ class DeviceData:
         error = float(np.mean(errs[-10:])) if n_iters is None else float(errs[-1])           # R/main.r:126-130
         return {"output_f": [f[0] for f in fin], "output_s": [f[1] for f in fin], "output_g": [f[2] for f in fin],
                 "row_clusters": [f[3] for f in fin], "col_clusters": [f[4] for f in fin],
-                "Error": error, "All_Error": errs, "tag": tag}
+                "Error": error, "All_Error": errs, "tag": tag,
+                "extras": {} if samples is None else {"row_samples": samples[0], "col_samples": samples[1]}}
 
 
 def k_sweep_on_device(dev: DeviceData, k_min: int = 3, k_max: int = 8, n_iters=None, seed: int = 0, group=None) -> List[dict]:
@@ -254,3 +263,22 @@ def shuffles_on_device(dev: DeviceData, n_clusts: int, num_repeats: int = 5, n_i
     reps = list(range(num_repeats))
     return run_jobs(reps, group=group,
                     runner=lambda r: dev.factorise(n_clusts, n_iters, seed + 1000 + r, shuffle_seed=seed * 7919 + r + 1, tag=f"shuffle={r}"))
+
+
+def stability_on_device(dev: DeviceData, k: int, n_stability: int = 5, sample_rate: float = 0.9, n_iters=None, seed: int = 0,
+                        group=None) -> List[dict]:
+    """The factorisations of ``stability_check`` (``R/stability_analysis.r:305-323``): the draws follow
+    ``subsample_views`` (shared draws for equal extents; the empty-row / empty-column trimming is vacuous on the
+    strictly positive pre-processed data kept on the device), the sub-samples are gathered on the device."""
+    rng = np.random.default_rng(seed)
+    draws = []
+    for _ in range(n_stability):
+        rows, cols = [], []
+        for v, (n, m) in enumerate(dev.data_shapes):
+            same_r = v > 0 and n == dev.data_shapes[0][0]
+            same_c = v > 0 and m == dev.data_shapes[0][1]
+            rows.append(rows[0] if same_r else rng.choice(n, int(n * sample_rate), replace=False))      # :114-118, :230
+            cols.append(cols[0] if same_c else rng.choice(m, int(m * sample_rate), replace=False))      # :119-123, :231
+        draws.append((rows, cols))
+    return run_jobs(list(range(n_stability)), group=group,
+                    runner=lambda r: dev.factorise(k, n_iters, seed + 2000 + r, samples=draws[r], tag=f"stability={r}"))

@@ -666,7 +666,7 @@ namespace {
 // matrix_normalisation (R/utils.r:20-27, 86-88) run on the device, fused into the conversion.
 // Source of the staging image: the host matrix x, or (x == NULL) a pseudo-random permutation of the
 // entries of another view's device copy (shuffle_src, see resnmtf_shuffle_view).
-struct ShuffleSrc { const float* X32; int ldx; unsigned long long seed; };
+struct ShuffleSrc { const float* X32; int ldx; unsigned long long seed; const int* rows; const int* cols; };   // rows != NULL: sub-sample
 int upload_view(resnmtf_handle* h, int v, const double* x, bool raw, int* was_negative, const ShuffleSrc* shuffle_src = nullptr) {
   if (int rc = check_view(h, v)) return rc;
   if (!x && !shuffle_src) return h->fail(RESNMTF_ERR_INVALID, "x is NULL");
@@ -690,8 +690,12 @@ int upload_view(resnmtf_handle* h, int v, const double* x, bool raw, int* was_ne
   int neg_host = 0;
   if (x) e = hipMemcpyAsync(staging, x, count * sizeof(double), hipMemcpyHostToDevice, h->stream);
   else {
-    hipLaunchKernelGGL(shuffle_gather_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream, shuffle_src->X32,
-                       shuffle_src->ldx, vs.n, vs.m, shuffle_src->seed, staging);
+    if (shuffle_src->rows)
+      hipLaunchKernelGGL(subsample_gather_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream, shuffle_src->X32,
+                         shuffle_src->ldx, shuffle_src->rows, vs.n, shuffle_src->cols, vs.m, staging);
+    else
+      hipLaunchKernelGGL(shuffle_gather_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream, shuffle_src->X32,
+                         shuffle_src->ldx, vs.n, vs.m, shuffle_src->seed, staging);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemsetAsync(vs.X32, 0, (size_t)vs.n_pad * vs.ldx * sizeof(float), h->stream);
@@ -756,8 +760,31 @@ int resnmtf_shuffle_view(resnmtf_handle* dst, int v, resnmtf_handle* src, int v_
   const ViewState& b = src->views[v_src];
   HIP_TRY(dst, hipSetDevice(dst->opt.device_id));
   HIP_TRY(dst, hipStreamSynchronize(src->stream));
-  const ShuffleSrc sh{b.X32, b.ldx, seed};
+  const ShuffleSrc sh{b.X32, b.ldx, seed, nullptr, nullptr};
   return upload_view(dst, v, nullptr, normalise != 0, nullptr, &sh);
+}
+
+int resnmtf_subsample_view(resnmtf_handle* dst, int v, resnmtf_handle* src, int v_src, const int* rows, const int* cols) {
+  if (int rc = check_view(dst, v)) return rc;
+  if (!src || v_src < 0 || v_src >= src->V) return dst->fail(RESNMTF_ERR_INVALID, "bad source handle / view");
+  if (!rows || !cols) return dst->fail(RESNMTF_ERR_INVALID, "rows / cols are NULL");
+  const ViewState& a = dst->views[v];
+  const ViewState& b = src->views[v_src];
+  if (!a.owned || !b.owned || !b.has_x) return dst->fail(RESNMTF_ERR_STATE, "both views must be owned and the source uploaded");
+  if (dst->opt.device_id != src->opt.device_id) return dst->fail(RESNMTF_ERR_INVALID, "handles live on different devices");
+  for (int r = 0; r < a.n; ++r) if (rows[r] < 0 || rows[r] >= b.n) return dst->fail(RESNMTF_ERR_INVALID, "row index out of range");
+  for (int c = 0; c < a.m; ++c) if (cols[c] < 0 || cols[c] >= b.m) return dst->fail(RESNMTF_ERR_INVALID, "column index out of range");
+  HIP_TRY(dst, hipSetDevice(dst->opt.device_id));
+  HIP_TRY(dst, hipStreamSynchronize(src->stream));
+  int* idx = nullptr;
+  HIP_TRY(dst, hipMalloc(reinterpret_cast<void**>(&idx), ((size_t)a.n + a.m) * sizeof(int)));
+  hipError_t e = hipMemcpy(idx, rows, (size_t)a.n * sizeof(int), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(idx + a.n, cols, (size_t)a.m * sizeof(int), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(idx); return dst->fail_hip("subsample_view", e); }
+  const ShuffleSrc sh{b.X32, b.ldx, 0ull, idx, idx + a.n};
+  const int rc = upload_view(dst, v, nullptr, false, nullptr, &sh);      // sub-samples are NOT re-normalised (Appendix B11)
+  (void)hipFree(idx);
+  return rc;
 }
 
 int resnmtf_get_view(resnmtf_handle* h, int v, double* x) {

@@ -122,6 +122,14 @@ class Engine:
         """``shuffle_view`` (``R/obtain_bicl.r:11-22``) of another engine's view, drawn on the device."""
         self._check(self._lib.resnmtf_shuffle_view(self._h, v, other._h, v_src, int(seed), 1 if normalise else 0))
 
+    def subsample_view_from(self, v: int, other: "Engine", v_src: int, rows, cols):
+        """The sub-sample ``X[rows, cols]`` of another engine's view (``R/stability_analysis.r:230-249``), gathered
+        on the device; this engine's view v must have the shape ``(len(rows), len(cols))``."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32); cols = np.ascontiguousarray(cols, dtype=np.int32)
+        if len(rows) != self.n_rows[v] or len(cols) != self.n_cols[v]:
+            raise ValueError("index counts must equal the view's shape")
+        self._check(self._lib.resnmtf_subsample_view(self._h, v, other._h, v_src, _ip(rows), _ip(cols)))
+
     def get_view(self, v: int) -> np.ndarray:
         """The device copy of the view's data (fp32 precision) as an fp64 matrix."""
         x = np.zeros((self.n_rows[v], self.n_cols[v]), order="F")

@@ -144,4 +144,26 @@ def test_k_sweep_and_shuffles_from_one_upload():
         np.testing.assert_allclose(r["output_f"][0].sum(0), 1.0, atol=1e-12)
         assert r["Error"] > 10 * sweep[1]["Error"]
     assert not np.array_equal(shuf[0]["output_f"][0], shuf[1]["output_f"][0])
+    stab = batched.stability_on_device(dev, 3, n_stability=2, n_iters=200)
+    for r in stab:
+        rows = r["extras"]["row_samples"][0]
+        assert r["output_f"][0].shape == (162, 3) and len(set(rows)) == 162
+        assert sorted(r["row_clusters"][0].sum(0)) == sorted(rc[rows].sum(0))     # the planted blocks, sub-sampled
     dev.close()
+
+
+@pytest.mark.gpu
+def test_device_subsample_is_the_index_gather():
+    from resnmtf_amd import synth
+    from resnmtf_amd.engine import Engine
+    x = synth.planted_view(90, 70, 3, 4)
+    base = Engine([90], [70], [3]); base.set_view(0, x)
+    rng = np.random.default_rng(0)
+    rows = rng.choice(90, 40, replace=False); cols = rng.choice(70, 33, replace=False)
+    e = Engine([40], [33], [3])
+    e.subsample_view_from(0, base, 0, rows, cols)
+    np.testing.assert_array_equal(e.get_view(0), base.get_view(0)[np.ix_(rows, cols)])      # not re-normalised (B11)
+    from resnmtf_amd.engine import ResnmtfError
+    with pytest.raises(ResnmtfError, match="out of range"):
+        e.subsample_view_from(0, base, 0, rows + 60, cols)
+    e.close(); base.close()
