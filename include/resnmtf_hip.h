@@ -61,7 +61,8 @@ typedef struct resnmtf_options {
   int device_id;          /* HIP device ordinal; one process per GPU (default 0) */
   void* stream;           /* hipStream_t to enqueue on; NULL = library-owned stream */
   int use_graph;          /* 1 (default): capture one sweep into a hipGraph and replay it */
-  int check_every;        /* convergence mode: sweeps enqueued per host-side check (default 8) */
+  int check_every;        /* convergence mode: sweeps enqueued per host-side check (default 32; launches after the stop
+                             test fired return at once) */
   int target_workgroups;  /* waves per streaming pass (sizes splits x waves-per-workgroup); 0 = default 4096 */
   int time_kernels;       /* 1: bracket every streaming-pass launch with HIP events (eager mode) */
   /* tuning overrides of the streaming-pass geometry (0 = automatic), see DESIGN.md section 5 */

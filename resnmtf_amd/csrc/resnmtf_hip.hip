@@ -466,7 +466,7 @@ void resnmtf_default_options(resnmtf_options* o) {
   o->device_id = 0;
   o->stream = nullptr;
   o->use_graph = 1;
-  o->check_every = 8;
+  o->check_every = 32;     // (sweeps after the stop test fired are empty launches: ~2 us each)
 }
 
 const char* resnmtf_last_error(const resnmtf_handle* h) {

@@ -37,7 +37,7 @@ def device_count() -> int:
 class Engine:
     def __init__(self, n_rows: Sequence[int], n_cols: Sequence[int], k: Sequence[int],
                  owned: Optional[Sequence[bool]] = None, device_id: int = 0, stream: int = 0,
-                 use_graph: bool = True, check_every: int = 8, target_workgroups: int = 0,
+                 use_graph: bool = True, check_every: int = 32, target_workgroups: int = 0,
                  time_kernels: bool = False, pass_waves: int = 0, pass_splits_xg: int = 0,
                  pass_splits_xtf: int = 0, pass_lds_pad_kb: int = 0, update_blocks: int = 0, no_pitch_pad: bool = False,
                  kk_mode: int = 0, bf16_split: int = 0, replicate_f: bool = False):
