@@ -27,7 +27,10 @@ import torch  # noqa: E402  (device memory for the stamp buffer)
 
 lib = _lib.load()
 lib.resnmtf_debug_set_stamp_buffer.argtypes = [C.c_void_p]
-prob = synth.config(cfg)
+if "x" in cfg:
+    n_, m_, k_ = (int(t) for t in cfg.split("x")); prob = synth.make_problem([(n_, m_)], k_)
+else:
+    prob = synth.config(cfg)
 n, m = prob.data[0].shape
 e = Engine([n], [m], [prob.k], use_graph=False, kk_mode=kk_mode)
 e.set_view(0, prob.data[0]); e.set_restrictions(); e.set_factors(0, prob.init_f[0], prob.init_s[0], prob.init_g[0])
