@@ -162,7 +162,11 @@ def run_sharded(args) -> dict:
     # every rank builds only the view it owns (same seeds as synth.make_problem) + all initial factors
     prob = sharded.local_problem(n_views, (n, m), k, phi=200.0, owned=[rank])
     drv = sharded.ShardedSweep(prob, owner_of=list(range(n_views)), rank=rank, world=world, device_index=local_rank,
-                               replicate_f=(os.environ.get("RESNMTF_NO_REPLICATE") != "1"))
+                               replicate_f=("force" if os.environ.get("RESNMTF_FORCE_REPLICATE") == "1" else
+                                            os.environ.get("RESNMTF_NO_REPLICATE") != "1"),
+                               allgather_blocks=(os.environ.get("RESNMTF_NO_ALLGATHER") != "1"),
+                               **({"serial_exchange": os.environ["RESNMTF_SERIAL_EXCHANGE"] == "1"}
+                                  if "RESNMTF_SERIAL_EXCHANGE" in os.environ else {}))
     if os.environ.get("RESNMTF_FORCE_BCAST") == "1":      # rehearsal: issue the F broadcast even with one rank
         drv.plan[0]["F"] = True
     drv.run(args.warmup)
@@ -176,6 +180,7 @@ def run_sharded(args) -> dict:
     dt = float(tmax.item())
     errs = drv.mean_errors()
     replicated = any(drv.replicated)
+    allgather = drv._allgather_blocks
     drv.close()
     dist.destroy_process_group()
     if rank != 0:
@@ -185,7 +190,8 @@ def run_sharded(args) -> dict:
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{n_views} phi-coupled views 10000x2000 (all rows shared, phi=200), k=16, one view per GPU, "
-                               + ("F chain replicated on every rank (its inputs broadcast once per sweep over RCCL), "
+                               + (("F chain replicated on every rank (its inputs: one RCCL all-gather per sweep), " if allgather else
+                                   "F chain replicated on every rank (its inputs broadcast once per sweep over RCCL), ")
                                   if replicated else "F exchanged by ordered RCCL broadcasts, ") + "Gauss-Seidel order kept exactly",
                    "n_views": n_views, "rows": n, "cols": m, "k": k,
                    "final_error": float(errs[-1]) if len(errs) else None},

@@ -43,7 +43,10 @@ enum {
 
 /* factor selectors for resnmtf_factor_device_ptr */
 enum { RESNMTF_FACTOR_F = 0, RESNMTF_FACTOR_G = 1, RESNMTF_FACTOR_S = 2,
-       RESNMTF_FACTOR_FBLOCK = 3 /* replicate_f: the F update's inputs [U slabs | Ma_F | Md_F | lambda], contiguous */ };
+       RESNMTF_FACTOR_FBLOCK = 3, /* replicate_f: the F update's inputs [U (X.G, one f32 slab) | Ma_F | Md_F | lambda], contiguous */
+       RESNMTF_FACTOR_FBLOCK_ALL = 4 /* replicate_f: the blocks of ALL views, contiguous in view order (v is ignored beyond its
+                                        range check); equal-shaped views have equal block sizes, so one in-place all-gather
+                                        over ranks that own one view each refreshes every block */ };
 
 /* phases of one view's update inside a sweep (R/update_steps.r:282-314) */
 enum {
@@ -51,7 +54,12 @@ enum {
   RESNMTF_PHASE_G = 1, /* Xt.F pass, update_g (R/update_steps.r:180-207), X.G' pass; update_s (220-240),
                           update_lm x2 (249-251, 312-313) and calculate_error (R/utils.r:157-166) ride in
                           the X.G' launch */
-  RESNMTF_PHASE_S = 2  /* no work: marks the point after which the view's new S may be exchanged */
+  RESNMTF_PHASE_S = 2, /* no work: marks the point after which the view's new S may be exchanged */
+  RESNMTF_PHASE_F_ALL = 3 /* update_f of EVERY view whose F inputs this handle holds (owned views and, with replicate_f, the
+                             others), in view order; `v` only has to be a valid view.  F_w' does not read G or S of this
+                             sweep, so hoisting the F updates of a sweep in front of its PHASE_G calls changes nothing.
+                             One launch (f_chain_kernel) when k <= 16, the views have equal row counts, share their rows in
+                             the same order and at most one of them is owned; one launch per view otherwise */
 };
 
 typedef struct resnmtf_handle resnmtf_handle;
@@ -83,11 +91,13 @@ typedef struct resnmtf_options {
                                1e-5 ... 6e-5 of the fp64 reference instead of 1e-6 ... 8e-6 (bar 1e-4);
                              2 plain v_mfma_f32_16x16x4_f32 */
   int replicate_f;        /* view-sharded use (phase API): 1 = every rank keeps, for EVERY view, the inputs of its F
-                             update (the X.G slabs, the two k x k coefficient matrices, lambda) in one contiguous
-                             exchange block (RESNMTF_FACTOR_FBLOCK) and may run RESNMTF_PHASE_F on views it does
-                             not own: the host broadcasts the block after the owner's PHASE_G and every rank
+                             update (X.G folded into one f32 slab, the two k x k coefficient matrices, lambda) in one
+                             contiguous exchange block (RESNMTF_FACTOR_FBLOCK) and may run RESNMTF_PHASE_F on views it does
+                             not own: the host moves the blocks once per sweep (one all-gather, or one broadcast per
+                             view) after the owners' PHASE_G and every rank
                              computes the phi-coupled F chain locally -- identical kernels on identical bytes,
                              so bitwise the same F everywhere -- instead of waiting for N serial F broadcasts */
+  int no_f_chain;         /* 1: RESNMTF_PHASE_F_ALL always issues one launch per view (A/B testing) */
 } resnmtf_options;
 
 typedef struct resnmtf_pass_timing {

@@ -14,8 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libresnmtf_hip.so")
 
 OK = 0
 ERR_NAMES = {1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "ALLOC", 5: "STATE"}
-FACTOR_F, FACTOR_G, FACTOR_S, FACTOR_FBLOCK = 0, 1, 2, 3
-PHASE_F, PHASE_G, PHASE_S = 0, 1, 2
+FACTOR_F, FACTOR_G, FACTOR_S, FACTOR_FBLOCK, FACTOR_FBLOCK_ALL = 0, 1, 2, 3, 4
+PHASE_F, PHASE_G, PHASE_S, PHASE_F_ALL = 0, 1, 2, 3
 MAX_K = 64
 
 
@@ -32,6 +32,7 @@ class Options(C.Structure):
         ("time_kernels", C.c_int), ("pass_waves", C.c_int), ("pass_splits_xg", C.c_int),
         ("pass_splits_xtf", C.c_int), ("pass_lds_pad_kb", C.c_int), ("update_blocks", C.c_int),
         ("no_pitch_pad", C.c_int), ("kk_mode", C.c_int), ("bf16_split", C.c_int), ("replicate_f", C.c_int),
+        ("no_f_chain", C.c_int),
     ]
 
 

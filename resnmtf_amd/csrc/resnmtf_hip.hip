@@ -54,8 +54,9 @@ struct ViewState {
   float *Pxg = nullptr, *Pxtf = nullptr, *Paux_xg = nullptr, *Paux_xtf = nullptr;
   int *cnt_xg = nullptr, *cnt_xtf = nullptr;
   int rpbF = 16, nblkF = 1, rpbG = 16, nblkG = 1;
-  void* fblk = nullptr;              // replicate_f: [Pxg slabs | Ma_F | Md_F | lambda] contiguous (the F-update's inputs)
-  size_t fblk_bytes = 0;
+  void* fblk = nullptr;              // replicate_f: [Usum | Ma_F | Md_F | lambda] contiguous (the F-update's inputs), a
+  size_t fblk_bytes = 0;             // slice of the handle's arena; Usum = the X.G split slabs folded into one f32 slab
+  float* Usum = nullptr;
   bool f_replica = false;            // non-owned view whose F update runs here too (replicate_f)
   bool pp_xg = false, pp_xtf = false; // k <= 16, streamed geometry: ping-pong prefetch form of the pass (UNROLL 4)
   int kk_mode = 0;                   // 0 = A: Gram partials from the update kernels, k x k job = workgroup 0
@@ -90,6 +91,11 @@ struct resnmtf_handle {
   int graph_multi_sweeps = 0;
   double graph_tol = -2.0;
   int n_cu = 256;                     // compute units of the device (multiProcessorCount)
+  ChainArgs<8> chain{};               // RESNMTF_PHASE_F_ALL: the F updates of every view in one launch (when eligible)
+  int chain_views = 0;                // 0 = not eligible: one launch per view
+  int chain_blocks = 0;
+  void* fblk_arena = nullptr;         // replicate_f: the F exchange blocks of all views, in view order
+  size_t fblk_arena_bytes = 0;
   // pass timing (eager mode)
   std::vector<hipEvent_t> ev;         // pairs
   std::vector<int> ev_kind;           // 0 = xg, 1 = xtf per pair
@@ -123,7 +129,7 @@ hipError_t dev_alloc_zero(T** p, size_t count) {
 }
 
 void free_view(ViewState& v) {
-  if (v.fblk) { (void)hipFree(v.fblk); v.fblk = nullptr; v.Pxg = nullptr; v.Ma_F = nullptr; v.Md_F = nullptr; v.lambda = nullptr; }
+  if (v.fblk) { v.fblk = nullptr; v.Usum = nullptr; v.Ma_F = nullptr; v.Md_F = nullptr; v.lambda = nullptr; }   // arena slices
   void* ptrs[] = {v.X32, v.Xt32, v.xnorm2, v.F, v.G, v.S, v.lambda, v.mu, v.F32, v.G32, v.T32, v.Pxg, v.Pxtf,
                   v.Paux_xg, v.Paux_xtf, v.cnt_xg, v.cnt_xtf, v.partF, v.partG, v.FtF, v.FtFS, v.cF, v.Ma_F, v.Md_F, v.Ma_G, v.Md_G};
   for (void* p : ptrs)
@@ -218,6 +224,9 @@ hipError_t set_all_attrs() {
   TRY_ATTR(set_smem_attrs<48>()); TRY_ATTR(set_smem_attrs<64>());
   TRY_ATTR((set_pass_attr<1, 4, 8>())); TRY_ATTR((set_pass_attr<1, 8, 8>())); TRY_ATTR((set_pass_attr<1, 8, 4>())); TRY_ATTR((set_pass_attr<1, 16, 8>()));
   TRY_ATTR((set_pass_attr<2, 8, 4>())); TRY_ATTR((set_pass_attr<3, 8, 4>())); TRY_ATTR((set_pass_attr<4, 8, 4>()));
+  TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&f_chain_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f_chain_smem_bytes<2>()));
+  TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&f_chain_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f_chain_smem_bytes<4>()));
+  TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&f_chain_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f_chain_smem_bytes<8>()));
 #undef TRY_ATTR
   return hipSuccess;
 }
@@ -296,6 +305,19 @@ void launch_pass_plain(resnmtf_handle* h, PassArgs a, int NT, bool xg) {
 #undef LAUNCH_PLAIN
 }
 
+template <int NVB>
+ChainArgs<NVB> narrow_chain(const ChainArgs<8>& c) {
+  ChainArgs<NVB> a{};
+  a.len = c.len; a.k = c.k; a.n_views = c.n_views; a.rows_per_block = c.rows_per_block;
+  a.emit = c.emit; a.W32e = c.W32e; a.parte = c.parte; a.restricted = c.restricted;
+  for (int v = 0; v < NVB; ++v) {
+    a.W[v] = c.W[v]; a.U[v] = c.U[v]; a.Ma[v] = c.Ma[v]; a.Md[v] = c.Md[v]; a.lm[v] = c.lm[v];
+    a.sigma[v] = c.sigma[v]; a.n_other[v] = c.n_other[v]; a.cmask[v] = c.cmask[v];
+    for (int w = 0; w < NVB; ++w) a.weight[v][w] = c.weight[v][w];
+  }
+  return a;
+}
+
 // kind: 0 = F update, 1 = G update, 2 = mode A run prologue: partials of the current G, nothing updated
 void launch_update(resnmtf_handle* h, const ViewState& v, int kind, bool check_done) {
   UpdateArgs a = kind == 0 ? v.argF : v.argG;
@@ -328,18 +350,46 @@ void launch_update(resnmtf_handle* h, const ViewState& v, int kind, bool check_d
 #undef LAUNCH_UPD_K
 }
 
+// RESNMTF_PHASE_F_ALL: update_f of every view in view order (one launch when the chain is eligible)
+void enqueue_phase_f_all(resnmtf_handle* h) {
+  if (h->chain_views > 0) {
+    const size_t smem = h->chain_views <= 2 ? f_chain_smem_bytes<2>() : h->chain_views <= 4 ? f_chain_smem_bytes<4>() : f_chain_smem_bytes<8>();
+    if (h->chain_views <= 2) {
+      ChainArgs<2> a = narrow_chain<2>(h->chain);
+      hipLaunchKernelGGL(f_chain_kernel<2>, dim3(h->chain_blocks), dim3(512), smem, h->stream, a);
+    } else if (h->chain_views <= 4) {
+      ChainArgs<4> a = narrow_chain<4>(h->chain);
+      hipLaunchKernelGGL(f_chain_kernel<4>, dim3(h->chain_blocks), dim3(512), smem, h->stream, a);
+    } else {
+      hipLaunchKernelGGL(f_chain_kernel<8>, dim3(h->chain_blocks), dim3(512), smem, h->stream, h->chain);
+    }
+    return;
+  }
+  for (const auto& v : h->views)
+    if (v.owned || v.f_replica) launch_update(h, v, 0, false);
+}
+
 // ---- the phases of one view (see the header comment)
 void enqueue_phase_f(resnmtf_handle* h, const ViewState& v, bool checked) { launch_update(h, v, 0, checked); }
+// replicate_f: the X.G split slabs of an owned view -> the one f32 slab of its exchange block (what every
+// rank's F update of this view reads, the owner's included: a third of the bytes on the wire at c2)
+void launch_fold(resnmtf_handle* h, const ViewState& v) {
+  if (!v.Usum) return;
+  const int quads = v.n_pad * v.KP / 4;
+  hipLaunchKernelGGL(slab_fold_kernel, dim3(ceil_div(quads, 256)), dim3(256), 0, h->stream, v.Pxg, v.nsplit_xg, quads, v.Usum);
+}
 void enqueue_phase_g(resnmtf_handle* h, const ViewState& v, double tol, bool checked) {
   launch_pass(h, v, false, 1, tol, checked);
   launch_update(h, v, 1, checked);
   launch_pass(h, v, true, 1, tol, checked);
+  launch_fold(h, v);
 }
 // run prologue of one view: X.G launch whose kk_s runs in mode 0 (F coefficients from the current S, G);
 // mode A first emits the fp64 partials of the current G so that a resumed run is bitwise identical
 void enqueue_prologue(resnmtf_handle* h, const ViewState& v) {
   if (v.kk_mode == 0) launch_update(h, v, 2, false);
   launch_pass(h, v, true, 0, -1.0, false);
+  launch_fold(h, v);
 }
 
 void enqueue_sweep(resnmtf_handle* h, double tol) {
@@ -545,6 +595,18 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
   if ((e = dev_alloc_zero(&h->ctl, 1)) != hipSuccess) return bail(e, "hipMalloc ctl");
   h->err_cap = 1024;
   if ((e = dev_alloc_zero(&h->err, (size_t)h->err_cap * n_views)) != hipSuccess) return bail(e, "hipMalloc err");
+  // replicate_f: one arena holds the F exchange block of every view, in view order (equal-shaped views
+  // give equal strides, so that one in-place all-gather moves every rank's block -- sharded.py)
+  auto fblk_usum_bytes = [](const ViewState& vs) { return ((size_t)vs.n_pad * vs.KP * sizeof(float) + 255) / 256 * 256; };
+  auto fblk_size = [&](const ViewState& vs) {
+    return (fblk_usum_bytes(vs) + (2 * (size_t)vs.k * vs.k + (size_t)vs.k) * sizeof(double) + 255) / 256 * 256;
+  };
+  if (o.replicate_f) {
+    for (const auto& vs : h->views) h->fblk_arena_bytes += fblk_size(vs);
+    if ((e = hipMalloc(&h->fblk_arena, h->fblk_arena_bytes)) != hipSuccess) return bail(e, "hipMalloc F exchange blocks");
+    if ((e = hipMemset(h->fblk_arena, 0, h->fblk_arena_bytes)) != hipSuccess) return bail(e, "hipMemset F exchange blocks");
+  }
+  size_t fblk_off = 0;
   for (int v = 0; v < n_views; ++v) {
     ViewState& vs = h->views[v];
     const size_t kk = (size_t)vs.k * vs.k;
@@ -590,13 +652,12 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     // (the sharded driver broadcasts it from the owner and runs the F update of coupled views everywhere)
     const size_t pxg_floats = (size_t)vs.nsplit_xg * vs.n_pad * vs.KP;
     if (o.replicate_f) {
-      const size_t pxg_bytes = (pxg_floats * sizeof(float) + 255) / 256 * 256;
-      vs.fblk_bytes = pxg_bytes + (2 * kk + (size_t)vs.k) * sizeof(double);
-      if ((e = hipMalloc(&vs.fblk, vs.fblk_bytes)) != hipSuccess) return bail(e, "hipMalloc F exchange block");
-      if ((e = hipMemset(vs.fblk, 0, vs.fblk_bytes)) != hipSuccess) return bail(e, "hipMemset F exchange block");
-      char* base = static_cast<char*>(vs.fblk);
-      vs.Pxg = reinterpret_cast<float*>(base);
-      vs.Ma_F = reinterpret_cast<double*>(base + pxg_bytes);
+      vs.fblk_bytes = fblk_size(vs);
+      char* base = static_cast<char*>(h->fblk_arena) + fblk_off;
+      fblk_off += vs.fblk_bytes;
+      vs.fblk = base;
+      vs.Usum = reinterpret_cast<float*>(base);
+      vs.Ma_F = reinterpret_cast<double*>(base + fblk_usum_bytes(vs));
       vs.Md_F = vs.Ma_F + kk;
       vs.lambda = vs.Md_F + kk;
       if (!vs.owned) {
@@ -606,9 +667,9 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
       }
     }
     if (!vs.owned) continue;
+    if ((e = dev_alloc_zero(&vs.Pxg, pxg_floats)) != hipSuccess) return bail(e, "hipMalloc Pxg");
     if (!o.replicate_f) {
       if ((e = dev_alloc_zero(&vs.lambda, (size_t)vs.k)) != hipSuccess) return bail(e, "hipMalloc lambda");
-      if ((e = dev_alloc_zero(&vs.Pxg, pxg_floats)) != hipSuccess) return bail(e, "hipMalloc Pxg");
       for (double** pp : {&vs.Ma_F, &vs.Md_F})
         if ((e = dev_alloc_zero(pp, kk)) != hipSuccess) return bail(e, "hipMalloc kxk");
     }
@@ -652,6 +713,7 @@ int resnmtf_destroy(resnmtf_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   destroy_graphs(h);
   for (auto& v : h->views) free_view(v);
+  if (h->fblk_arena) (void)hipFree(h->fblk_arena);
   if (h->ctl) (void)hipFree(h->ctl);
   if (h->err) (void)hipFree(h->err);
   for (auto& evt : h->ev)
@@ -1169,6 +1231,46 @@ int resnmtf_set_shared_cols(resnmtf_handle* h, int v, int w, int count, const in
   return set_shared(h, v, w, count, idx_v, idx_w, false);
 }
 
+// RESNMTF_PHASE_F_ALL in one launch (f_chain_kernel): every view holds the inputs of its F update here
+// (owned, or an F replica), k <= 16 in hand-off mode A, equal row counts and row blocking, every coupling
+// through identity row maps, at most one owned view, at most 8 views.  Otherwise one launch per view.
+static void build_chain(resnmtf_handle* h) {
+  h->chain_views = 0;
+  const int V = h->V;
+  if (V < 2 || V > 8 || h->opt.no_f_chain) return;
+  const ViewState& v0 = h->views[0];
+  int n_owned = 0, emit = -1;
+  for (int v = 0; v < V; ++v) {
+    const ViewState& vs = h->views[v];
+    if (!vs.owned && !vs.f_replica) return;
+    if (vs.KP != 16 || vs.kk_mode != 0 || vs.n != v0.n || vs.k != v0.k || vs.rpbF != v0.rpbF || vs.nblkF != v0.nblkF) return;
+    if (!vs.Usum && vs.nsplit_xg != 1) return;              // the kernel reads ONE product slab per view
+    if (vs.owned) { ++n_owned; emit = v; }
+    for (int c = 0; c < vs.argF.n_couple; ++c)
+      if (vs.argF.couple[c].map) return;                    // permuted shared rows: rows of different workgroups
+  }
+  if (n_owned > 1) return;
+  ChainArgs<8>& a = h->chain;
+  a = ChainArgs<8>{};
+  a.len = v0.n; a.k = v0.k; a.n_views = V; a.rows_per_block = v0.rpbF;
+  a.emit = emit;
+  a.W32e = emit >= 0 ? h->views[emit].F32 : nullptr;
+  a.parte = emit >= 0 ? h->views[emit].partF : nullptr;
+  for (int v = 0; v < V; ++v) {
+    const ViewState& vs = h->views[v];
+    const UpdateArgs& f = vs.argF;
+    a.W[v] = vs.F; a.U[v] = f.P; a.Ma[v] = vs.Ma_F; a.Md[v] = vs.Md_F; a.lm[v] = vs.lambda;
+    a.sigma[v] = f.sigma;
+    a.n_other[v] = (double)vs.n;
+    if (f.restricted) a.restricted |= 1u << v;
+    for (int c = 0; c < f.n_couple; ++c)
+      for (int w = 0; w < V; ++w)
+        if (f.couple[c].W == h->views[w].F) { a.cmask[v] |= 1u << w; a.weight[v][w] = f.couple[c].weight; }
+  }
+  h->chain_views = V;
+  h->chain_blocks = v0.nblkF;
+}
+
 // builds the kernel argument blocks (coupling tables included) from the host-side description
 static int build_args(resnmtf_handle* h) {
   const int V = h->V;
@@ -1184,6 +1286,7 @@ static int build_args(resnmtf_handle* h) {
     f = UpdateArgs{};
     f.len = vs.n; f.k = vs.k; f.W = vs.F; f.W32 = vs.F32; f.ld32 = vs.kk_mode == 0 ? vs.KP : 64;
     f.P = vs.Pxg; f.nsplit = vs.nsplit_xg; f.cols_pad = vs.n_pad;
+    if (vs.Usum) { f.P = vs.Usum; f.nsplit = 1; }      // replicate_f: the folded slab of the exchange block
     f.Ma = vs.Ma_F; f.Md = vs.Md_F; f.lm = vs.lambda; f.T32 = nullptr; f.part = vs.partF;
     f.rows_per_block = vs.rpbF; f.ctl = h->ctl;
     {
@@ -1271,6 +1374,7 @@ static int build_args(resnmtf_handle* h) {
       }
     }
   }
+  build_chain(h);
   return RESNMTF_OK;
 }
 
@@ -1303,7 +1407,7 @@ int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep) {
   if (int rc = check_view(h, v)) return rc;
   if (!h->prepared) return h->fail(RESNMTF_ERR_STATE, "resnmtf_prepare has not been called");
   const ViewState& vs = h->views[v];
-  if (!vs.owned && !(vs.f_replica && phase == RESNMTF_PHASE_F))
+  if (!vs.owned && !(vs.f_replica && phase == RESNMTF_PHASE_F) && phase != RESNMTF_PHASE_F_ALL)
     return h->fail(RESNMTF_ERR_STATE, "phase on a view this handle does not own");
   if (sweep < 0) return h->fail(RESNMTF_ERR_INVALID, "negative sweep index");
   if (sweep >= h->err_cap) return h->fail(RESNMTF_ERR_STATE, "sweep beyond the reserved error buffer (resnmtf_reserve_sweeps)");
@@ -1312,6 +1416,7 @@ int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep) {
     case RESNMTF_PHASE_F: enqueue_phase_f(h, vs, false); break;
     case RESNMTF_PHASE_G: enqueue_phase_g(h, vs, -1.0, false); break;
     case RESNMTF_PHASE_S: break;   // S is complete behind PHASE_G on the handle's stream
+    case RESNMTF_PHASE_F_ALL: enqueue_phase_f_all(h); break;
     default: return h->fail(RESNMTF_ERR_INVALID, "unknown phase");
   }
   HIP_TRY(h, hipGetLastError());
@@ -1453,6 +1558,9 @@ int resnmtf_factor_device_ptr(resnmtf_handle* h, int v, int which, void** ptr, s
     case RESNMTF_FACTOR_FBLOCK:
       if (!vs.fblk) return h->fail(RESNMTF_ERR_STATE, "no F exchange block: create the handle with replicate_f = 1");
       *ptr = vs.fblk; *bytes = vs.fblk_bytes; break;
+    case RESNMTF_FACTOR_FBLOCK_ALL:
+      if (!h->fblk_arena) return h->fail(RESNMTF_ERR_STATE, "no F exchange blocks: create the handle with replicate_f = 1");
+      *ptr = h->fblk_arena; *bytes = h->fblk_arena_bytes; break;
     default: return h->fail(RESNMTF_ERR_INVALID, "unknown factor selector");
   }
   return RESNMTF_OK;

@@ -36,7 +36,14 @@ every view of a phi-coupled component that spans several ranks, the INPUTS of it
 X.G slabs, the k x k coefficient matrices, lambda: one contiguous exchange block) and runs that
 update itself -- the same kernel on the same bytes, hence bitwise the same F everywhere.  The block
 of view v is broadcast once per sweep after the owner's PHASE_G(v), off the chain; what remains
-on the critical path of a rank is N short F-update kernels plus its own two passes.
+on the critical path of a rank is N short F-update kernels plus its own two passes.  The block is
+compact: X.G folded into one f32 slab + two k x k matrices + lambda (0.64 MB at 10000 x 16).  When every
+rank owns exactly one view, all views are replicated and their blocks have one size (the weak-scaling
+layout of bench.py), the N broadcasts of a sweep become ONE in-place all-gather over the library's
+block arena (``RESNMTF_FACTOR_FBLOCK_ALL``) at the end of the sweep: one collective launch and one host
+call instead of N, and every xGMI link carries a block at the same time.  In that layout the F updates of a sweep are also hoisted
+to its start as one ``RESNMTF_PHASE_F_ALL`` (F_w' reads neither G nor S of the same sweep): one kernel launch
+walks the whole chain when the views share their rows in the same order.
 
 The engine is injected (``engine`` argument) so that the identical driver code runs in the CPU
 tests on a stand-in engine (no streams); in production it is ``resnmtf_amd.engine.Engine``.
@@ -48,10 +55,11 @@ from typing import Callable, Dict, List, Optional, Sequence
 import numpy as np
 
 from . import naming
-from ._lib import FACTOR_F, FACTOR_FBLOCK, FACTOR_G, FACTOR_S, PHASE_F, PHASE_G, PHASE_S
+from ._lib import (FACTOR_F, FACTOR_FBLOCK, FACTOR_FBLOCK_ALL, FACTOR_G, FACTOR_S, PHASE_F, PHASE_F_ALL, PHASE_G,
+                   PHASE_S)
 from .synth import Problem, planted_view, random_init
 
-_WHICH = {"F": FACTOR_F, "G": FACTOR_G, "S": FACTOR_S, "FBLOCK": FACTOR_FBLOCK}
+_WHICH = {"F": FACTOR_F, "G": FACTOR_G, "S": FACTOR_S, "FBLOCK": FACTOR_FBLOCK, "FBLOCK_ALL": FACTOR_FBLOCK_ALL}
 
 
 def exchange_plan(n_views: int, owner_of: Sequence[int], phi, xi, psi, row_shared, col_shared) -> List[Dict[str, bool]]:
@@ -228,6 +236,8 @@ class ShardedSweep:
         rep = replicated_views(self.n_views, self.owner_of, prob.phi, row_sh)
         if replicate_f is None:       # default: on with the HIP engine, off with an injected (stand-in) engine
             replicate_f = engine is None and engine_factory is None
+        if replicate_f == "force":    # rehearsal of the replicated path with fewer ranks than it needs (bench.py, one GPU)
+            rep = [True] * self.n_views
         self.replicated = rep if (replicate_f and any(rep)) else [False] * self.n_views
         if any(self.replicated):      # the F blocks of replicated views travel instead of their F
             for v in range(self.n_views):
@@ -237,7 +247,9 @@ class ShardedSweep:
         self._xstream = None      # exchange stream
         self._ev_f = self._ev_g = None
         self._ev_recv: Dict[tuple, object] = {}      # (view, factor) -> event after its latest broadcast
-        self._serial = bool(engine_opts.pop("serial_exchange", False))   # one-stream fallback (diagnostic)
+        serial_opt = engine_opts.pop("serial_exchange", None)   # None: one stream in the all-gather layout, two otherwise
+        self._serial = bool(serial_opt)
+        engine_opts_allgather = bool(engine_opts.pop("allgather_blocks", True))
         if engine is not None:
             self.engine = engine
         elif engine_factory is not None:
@@ -251,8 +263,55 @@ class ShardedSweep:
                                           replicate_f=any(self.replicated), **engine_opts)
         self.sweeps_done = 0
         self._prepared = False
+        self._allgather_blocks = self._can_allgather(engine_opts_allgather)
+        # all-gather layout: the exchange sits between two dependent steps of the sweep (nothing to overlap it
+        # with), so it is issued on the compute stream itself -- measured with one rank on RCCL: 54.6 us per
+        # sweep against 90.0 us through a second stream and its event edges
+        if self._allgather_blocks and serial_opt is None and self._tstream is not None:
+            self._serial = True
+            self._xstream = self._tstream
+
+    def _can_allgather(self, wanted: bool) -> bool:
+        """One in-place all-gather per sweep instead of one block broadcast per view: every rank owns exactly
+        one view (view v on rank v), every view is replicated, and the blocks tile the arena evenly."""
+        if not wanted or not all(self.replicated) or self.owner_of != list(range(self.world)):
+            return False
+        if not hasattr(self.engine, "factor_tensor"):
+            return False
+        try:
+            arena = self.engine.factor_tensor(0, "FBLOCK_ALL")
+            blocks = [self.engine.factor_tensor(v, "FBLOCK") for v in range(self.n_views)]
+        except Exception:
+            return False
+        size = blocks[0].numel()
+        esz = arena.element_size()
+        return (arena.numel() == size * self.n_views and
+                all(b.numel() == size and b.data_ptr() == arena.data_ptr() + v * size * esz for v, b in enumerate(blocks)))
 
     # ------------------------------------------------------------------
+    def _allgather(self):
+        """Every rank's F exchange block to every rank (end of a sweep / after the run prologue)."""
+        arena = self.engine.factor_tensor(0, "FBLOCK_ALL")
+        two = self._tstream is not None and self._xstream is not self._tstream
+        if two:      # after the latest PHASE_F (last reader of the old blocks) and PHASE_G (writer of the own block)
+            for after in (self._ev_f, self._ev_g):
+                if after is not None:
+                    self._xstream.wait_event(after)
+        if self.dist.get_backend(self.group) == "nccl":
+            mine = self.engine.factor_tensor(self.rank, "FBLOCK")      # = arena[rank]: in place
+            self.dist.all_gather_into_tensor(arena, mine, group=self.group)
+        else:        # gloo has no device all-gather: same data movement as one broadcast per block (rehearsals, tests)
+            for v in range(self.n_views):
+                self.dist.broadcast(self.engine.factor_tensor(v, "FBLOCK"), src=v, group=self.group)
+        if two:
+            import torch
+            ev = self._ev_recv.get((0, "FBLOCK"))
+            if ev is None:
+                ev = torch.cuda.Event()
+                for v in range(self.n_views):
+                    self._ev_recv[(v, "FBLOCK")] = ev
+            ev.record(self._xstream)
+
     def _bcast(self, v: int, which: str):
         t = self.engine.factor_tensor(v, which)
         if self._tstream is None:                      # CPU stand-in engine: plain blocking broadcast
@@ -292,7 +351,9 @@ class ShardedSweep:
             # only what the phase reads: PHASE_F(v) its own exchange block and the broadcast F mirrors (the
             # replicated ones are computed on this very stream); PHASE_G / PHASE_S the G and S mirrors --
             # NOT the latest broadcast of any kind, which would turn every sweep into a barrier
-            if phases[0] == PHASE_F:
+            if phases[0] == PHASE_F_ALL:     # every block (all-gather layout: one shared event)
+                waits = list({id(ev): ev for (w, which), ev in self._ev_recv.items() if which in ("F", "FBLOCK")}.values())
+            elif phases[0] == PHASE_F:
                 waits = [ev for (w, which), ev in self._ev_recv.items() if which == "F" or (which == "FBLOCK" and w == v)]
             else:
                 waits = [ev for (w, which), ev in self._ev_recv.items() if which in ("G", "S")]
@@ -303,7 +364,7 @@ class ShardedSweep:
         if two:
             ev = self._next_event()
             ev.record(self._tstream)
-            if phases[0] == PHASE_F:
+            if phases[0] in (PHASE_F, PHASE_F_ALL):
                 self._ev_f = ev
             else:
                 self._ev_g = ev
@@ -330,27 +391,37 @@ class ShardedSweep:
                 if self._tstream is not None and self._xstream is not self._tstream:
                     self._ev_g = self._next_event()
                     self._ev_g.record(self._tstream)
-                for v in range(self.n_views):
-                    if self.replicated[v]:
-                        self._bcast(v, "FBLOCK")
+                if self._allgather_blocks:
+                    self._allgather()
+                else:
+                    for v in range(self.n_views):
+                        if self.replicated[v]:
+                            self._bcast(v, "FBLOCK")
         if self.sweeps_done + n_sweeps > self._reserved:
             raise RuntimeError("reserve more sweeps before the first run() (errors are kept per sweep)")
         for _ in range(n_sweeps):
             t = self.sweeps_done
+            # all-gather layout: every F update of the sweep first, as ONE phase (one launch when the views share
+            # their rows in the same order).  Legal hoist: F_w' reads neither G nor S of this sweep.
+            hoist = self._allgather_blocks
+            if hoist:
+                self._phase(self.rank, (PHASE_F_ALL,), t, True)
             for v in range(self.n_views):
                 mine = self.owned[v]
-                if mine or self.replicated[v]:
+                if (mine or self.replicated[v]) and not hoist:
                     self._phase(v, (PHASE_F,), t, True)                      # reads the mirrors of coupled F_w (and v's block)
                 if self.plan[v]["F"]:
                     self._bcast(v, "F")
                 if mine:
                     self._phase(v, (PHASE_G, PHASE_S), t, self._gs_exchanged)  # reads G_w / S_w mirrors if exchanged
-                if self.replicated[v]:
+                if self.replicated[v] and not self._allgather_blocks:
                     self._bcast(v, "FBLOCK")                                 # next sweep's F update inputs, off the chain
                 if self.plan[v]["G"]:
                     self._bcast(v, "G")
                 if self.plan[v]["S"]:
                     self._bcast(v, "S")
+            if self._allgather_blocks:
+                self._allgather()                                            # next sweep's F update inputs of every view
             self.sweeps_done += 1
 
     # ------------------------------------------------------------------

@@ -98,12 +98,32 @@ def build_problem():
     return prob
 
 
+def build_problem_one_view_per_rank(world=2, identity=False):
+    """One view per rank with equal row counts (equal F exchange blocks): the layout in which the
+    blocks travel by one all-gather per sweep.  phi + xi coupled, rows shared at permuted positions."""
+    from resnmtf_amd.synth import Problem, planted_view, random_init
+    rng = np.random.default_rng(78)
+    shapes = [(96, 72 - 8 * v) for v in range(world)]
+    k = 5
+    data = [planted_view(n, m, k, 700 + v) for v, (n, m) in enumerate(shapes)]
+    inits = [random_init(n, m, k, 800 + v) for v, (n, m) in enumerate(shapes)]
+    # identity: every view lists the shared rows in the same order (what auto-naming gives): the F updates
+    # of a sweep then run as one fused launch (f_chain_kernel)
+    rown = [[f"r{i}" for i in (range(96) if (v == 0 or identity) else rng.permutation(96))] for v in range(world)]
+    coln = [[f"c{v}_{i}" for i in range(m)] for v, (_, m) in enumerate(shapes)]
+    off = 1.0 - np.eye(world)
+    prob = Problem(data, [i[0] for i in inits], [i[1] for i in inits], [i[2] for i in inits],
+                   1.5 * off, 0.4 * off, 0.0 * off, k, row_names=rown, col_names=coln)
+    prob.extras["shapes"] = shapes
+    return prob
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rank", type=int, required=True)
     ap.add_argument("--world", type=int, required=True)
     ap.add_argument("--port", type=int, required=True)
-    ap.add_argument("--mode", choices=["cpu", "gpu", "gpu_norep"], required=True)
+    ap.add_argument("--mode", choices=["cpu", "gpu", "gpu_norep", "gpu_allgather", "gpu_chain", "gpu_chain_off"], required=True)
     ap.add_argument("--sweeps", type=int, default=12)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
@@ -113,23 +133,27 @@ def main():
     import torch.distributed as dist
     from resnmtf_amd import sharded
     dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
-    prob = build_problem()
-    owner_of = [v % a.world for v in range(3)]
+    one_per_rank = a.mode in ("gpu_allgather", "gpu_chain", "gpu_chain_off")
+    prob = build_problem_one_view_per_rank(a.world, identity=a.mode != "gpu_allgather") if one_per_rank else build_problem()
+    n_v = len(prob.init_f)
+    owner_of = [v % a.world for v in range(n_v)]
     if a.mode == "cpu":
         drv = sharded.ShardedSweep(prob, owner_of, a.rank, a.world, engine_factory=lambda p, owned: OracleEngine(p, owned))
     else:
-        drv = sharded.ShardedSweep(prob, owner_of, a.rank, a.world, device_index=0, replicate_f=(a.mode == "gpu"))
-        assert any(drv.replicated) == (a.mode == "gpu")
+        opts = {"no_f_chain": True} if a.mode == "gpu_chain_off" else {}
+        drv = sharded.ShardedSweep(prob, owner_of, a.rank, a.world, device_index=0, replicate_f=(a.mode != "gpu_norep"), **opts)
+        assert any(drv.replicated) == (a.mode != "gpu_norep")
+        assert drv._allgather_blocks == one_per_rank
     drv.run(a.sweeps // 2)
     drv.run(a.sweeps - a.sweeps // 2)          # two calls: state carries over
     mirrors_ok = True
     if a.mode != "cpu":                          # every rank's copy of every F must be bitwise the owner's
         import torch
         drv.engine.synchronize(); torch.cuda.synchronize()
-        mine = [drv.engine.factor_tensor(v, "F").cpu().numpy().tobytes() for v in range(3)]
+        mine = [drv.engine.factor_tensor(v, "F").cpu().numpy().tobytes() for v in range(n_v)]
         allf = [None] * a.world
         dist.all_gather_object(allf, mine)
-        mirrors_ok = all(allf[r][v] == allf[owner_of[v]][v] for r in range(a.world) for v in range(3))
+        mirrors_ok = all(allf[r][v] == allf[owner_of[v]][v] for r in range(a.world) for v in range(n_v))
     errs = drv.mean_errors()
     res = drv.gather_results(0)
     drv.close()

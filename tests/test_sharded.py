@@ -53,6 +53,15 @@ def oracle_reference(sweeps=12):
                             row_names=prob.row_names, col_names=prob.col_names, n_iters=sweeps)
 
 
+def oracle_reference_one_view_per_rank(world=2, sweeps=12, identity=False):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_worker
+    from oracle import resnmtf_oracle as O
+    prob = dist_worker.build_problem_one_view_per_rank(world, identity=identity)
+    return O.res_nmtf_inner(prob.data, prob.init_f, prob.init_s, prob.init_g, prob.phi, prob.xi, prob.psi,
+                            row_names=prob.row_names, col_names=prob.col_names, n_iters=sweeps)
+
+
 def test_exchange_plan():
     from resnmtf_amd import naming
     from resnmtf_amd.sharded import exchange_plan
@@ -98,3 +107,38 @@ def test_sharded_hip_two_ranks_one_gpu(tmp_path, mode):
         assert rel_fro(got[f"output_f{v}"], ref["output_f"][v]) < 2e-5
         assert rel_fro(got[f"output_g{v}"], ref["output_g"][v]) < 2e-5
         assert rel_fro(got[f"output_s{v}"], ref["output_s"][v]) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_hip_allgather_layout(tmp_path, world):
+    """One view per rank, equal exchange blocks: the blocks travel once per sweep over the library's block
+    arena (one all-gather on RCCL; gloo, used here because the ranks share one GPU, moves the same bytes by
+    one broadcast per block).  Same results as the sequential oracle, every F mirror bitwise the owner's."""
+    got = launch("gpu_allgather", tmp_path, world=world)
+    assert bool(got["mirrors_ok"])
+    ref = oracle_reference_one_view_per_rank(world)
+    np.testing.assert_allclose(got["all_error"], ref["All_Error"], atol=2e-5, rtol=1e-4)
+    for v in range(world):
+        assert rel_fro(got[f"output_f{v}"], ref["output_f"][v]) < 2e-5
+        assert rel_fro(got[f"output_g{v}"], ref["output_g"][v]) < 2e-5
+        assert rel_fro(got[f"output_s{v}"], ref["output_s"][v]) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_sharded_hip_fused_f_chain(tmp_path, world):
+    """Views sharing their rows in the same order: RESNMTF_PHASE_F_ALL is one launch (f_chain_kernel, the 2 / 4 / 8
+    view instantiations).  Against the sequential oracle, and against the same run with one launch per view."""
+    got = launch("gpu_chain", tmp_path, world=world)
+    assert bool(got["mirrors_ok"])
+    ref = oracle_reference_one_view_per_rank(world, identity=True)
+    np.testing.assert_allclose(got["all_error"], ref["All_Error"], atol=2e-5, rtol=1e-4)
+    off = launch("gpu_chain_off", tmp_path, world=world)
+    np.testing.assert_allclose(got["all_error"], off["all_error"], atol=1e-12, rtol=1e-10)
+    for v in range(world):
+        assert rel_fro(got[f"output_f{v}"], ref["output_f"][v]) < 2e-5
+        assert rel_fro(got[f"output_g{v}"], ref["output_g"][v]) < 2e-5
+        assert rel_fro(got[f"output_s{v}"], ref["output_s"][v]) < 1e-4
+        assert rel_fro(got[f"output_f{v}"], off[f"output_f{v}"]) < 1e-10
+        assert np.array_equal(got[f"row_clusters{v}"], ref["row_clusters"][v])
