@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libresnmtf_hip.so")
 OK = 0
 ERR_NAMES = {1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "ALLOC", 5: "STATE"}
 FACTOR_F, FACTOR_G, FACTOR_S, FACTOR_FBLOCK, FACTOR_FBLOCK_ALL = 0, 1, 2, 3, 4
-PHASE_F, PHASE_G, PHASE_S, PHASE_F_ALL = 0, 1, 2, 3
+PHASE_F, PHASE_G, PHASE_S, PHASE_F_ALL, PHASE_LOCAL_SWEEP = 0, 1, 2, 3, 4
 MAX_K = 64
 
 

@@ -56,7 +56,7 @@ import numpy as np
 
 from . import naming
 from ._lib import (FACTOR_F, FACTOR_FBLOCK, FACTOR_FBLOCK_ALL, FACTOR_G, FACTOR_S, PHASE_F, PHASE_F_ALL, PHASE_G,
-                   PHASE_S)
+                   PHASE_LOCAL_SWEEP, PHASE_S)
 from .synth import Problem, planted_view, random_init
 
 _WHICH = {"F": FACTOR_F, "G": FACTOR_G, "S": FACTOR_S, "FBLOCK": FACTOR_FBLOCK, "FBLOCK_ALL": FACTOR_FBLOCK_ALL}
@@ -399,11 +399,18 @@ class ShardedSweep:
                             self._bcast(v, "FBLOCK")
         if self.sweeps_done + n_sweeps > self._reserved:
             raise RuntimeError("reserve more sweeps before the first run() (errors are kept per sweep)")
+        two_streams = self._tstream is not None and self._xstream is not self._tstream
         for _ in range(n_sweeps):
             t = self.sweeps_done
             # all-gather layout: every F update of the sweep first, as ONE phase (one launch when the views share
             # their rows in the same order).  Legal hoist: F_w' reads neither G nor S of this sweep.
             hoist = self._allgather_blocks
+            if hoist and not self._gs_exchanged and not two_streams:
+                # nothing crosses ranks inside the sweep: the rank's whole share in one library call
+                self.engine.phase(self.rank, PHASE_LOCAL_SWEEP, t)
+                self._allgather()
+                self.sweeps_done += 1
+                continue
             if hoist:
                 self._phase(self.rank, (PHASE_F_ALL,), t, True)
             for v in range(self.n_views):

@@ -98,7 +98,7 @@ def build_problem():
     return prob
 
 
-def build_problem_one_view_per_rank(world=2, identity=False):
+def build_problem_one_view_per_rank(world=2, identity=False, xi=0.4):
     """One view per rank with equal row counts (equal F exchange blocks): the layout in which the
     blocks travel by one all-gather per sweep.  phi + xi coupled, rows shared at permuted positions."""
     from resnmtf_amd.synth import Problem, planted_view, random_init
@@ -113,7 +113,7 @@ def build_problem_one_view_per_rank(world=2, identity=False):
     coln = [[f"c{v}_{i}" for i in range(m)] for v, (_, m) in enumerate(shapes)]
     off = 1.0 - np.eye(world)
     prob = Problem(data, [i[0] for i in inits], [i[1] for i in inits], [i[2] for i in inits],
-                   1.5 * off, 0.4 * off, 0.0 * off, k, row_names=rown, col_names=coln)
+                   1.5 * off, xi * off, 0.0 * off, k, row_names=rown, col_names=coln)
     prob.extras["shapes"] = shapes
     return prob
 
@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--port", type=int, required=True)
     ap.add_argument("--mode", choices=["cpu", "gpu", "gpu_norep", "gpu_allgather", "gpu_chain", "gpu_chain_off"], required=True)
     ap.add_argument("--sweeps", type=int, default=12)
+    ap.add_argument("--xi", type=float, default=0.4)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -134,7 +135,7 @@ def main():
     from resnmtf_amd import sharded
     dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
     one_per_rank = a.mode in ("gpu_allgather", "gpu_chain", "gpu_chain_off")
-    prob = build_problem_one_view_per_rank(a.world, identity=a.mode != "gpu_allgather") if one_per_rank else build_problem()
+    prob = build_problem_one_view_per_rank(a.world, identity=a.mode != "gpu_allgather", xi=a.xi) if one_per_rank else build_problem()
     n_v = len(prob.init_f)
     owner_of = [v % a.world for v in range(n_v)]
     if a.mode == "cpu":

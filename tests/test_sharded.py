@@ -23,13 +23,13 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch(mode, tmp_path, world=2, sweeps=12, timeout=600):
+def launch(mode, tmp_path, world=2, sweeps=12, timeout=600, xi=0.4):
     port = free_port()
     out = str(tmp_path / f"sharded_{mode}.npz")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "--rank", str(r),
                                "--world", str(world), "--port", str(port), "--mode", mode, "--sweeps", str(sweeps),
-                               "--out", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                               "--xi", str(xi), "--out", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(world)]
     logs = []
     for p in procs:
@@ -53,11 +53,11 @@ def oracle_reference(sweeps=12):
                             row_names=prob.row_names, col_names=prob.col_names, n_iters=sweeps)
 
 
-def oracle_reference_one_view_per_rank(world=2, sweeps=12, identity=False):
+def oracle_reference_one_view_per_rank(world=2, sweeps=12, identity=False, xi=0.4):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dist_worker
     from oracle import resnmtf_oracle as O
-    prob = dist_worker.build_problem_one_view_per_rank(world, identity=identity)
+    prob = dist_worker.build_problem_one_view_per_rank(world, identity=identity, xi=xi)
     return O.res_nmtf_inner(prob.data, prob.init_f, prob.init_s, prob.init_g, prob.phi, prob.xi, prob.psi,
                             row_names=prob.row_names, col_names=prob.col_names, n_iters=sweeps)
 
@@ -126,15 +126,16 @@ def test_sharded_hip_allgather_layout(tmp_path, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3, 5])
-def test_sharded_hip_fused_f_chain(tmp_path, world):
+@pytest.mark.parametrize("world,xi", [(2, 0.4), (3, 0.4), (5, 0.4), (2, 0.0), (4, 0.0)])
+def test_sharded_hip_fused_f_chain(tmp_path, world, xi):
     """Views sharing their rows in the same order: RESNMTF_PHASE_F_ALL is one launch (f_chain_kernel, the 2 / 4 / 8
-    view instantiations).  Against the sequential oracle, and against the same run with one launch per view."""
-    got = launch("gpu_chain", tmp_path, world=world)
+    view instantiations).  Against the sequential oracle, and against the same run with one launch per view.
+    xi = 0: only the F blocks cross ranks, the rank's share of a sweep is one RESNMTF_PHASE_LOCAL_SWEEP call."""
+    got = launch("gpu_chain", tmp_path, world=world, xi=xi)
     assert bool(got["mirrors_ok"])
-    ref = oracle_reference_one_view_per_rank(world, identity=True)
+    ref = oracle_reference_one_view_per_rank(world, identity=True, xi=xi)
     np.testing.assert_allclose(got["all_error"], ref["All_Error"], atol=2e-5, rtol=1e-4)
-    off = launch("gpu_chain_off", tmp_path, world=world)
+    off = launch("gpu_chain_off", tmp_path, world=world, xi=xi)
     np.testing.assert_allclose(got["all_error"], off["all_error"], atol=1e-12, rtol=1e-10)
     for v in range(world):
         assert rel_fro(got[f"output_f{v}"], ref["output_f"][v]) < 2e-5
