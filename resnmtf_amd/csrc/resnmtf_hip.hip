@@ -44,7 +44,8 @@ struct ViewState {
   int n = 0, m = 0, k = 0, KP = 16, NT = 1;
   bool owned = true, has_x = false, has_factors = false;
   int n_pad = 0, m_pad = 0;
-  int ldx = 0, ldxt = 0;         // leading dimensions of X32 / Xt32 (floats), kept off large powers of two
+  size_t ldx = 0, ldxt = 0;      // TILE strides of X32 / Xt32 (floats): tile t (64 columns) is a contiguous [rows_pad][64] block
+  size_t x32_floats = 0, xt32_floats = 0;
   float *X32 = nullptr, *Xt32 = nullptr;
   double* xnorm2 = nullptr;
   double *F = nullptr, *G = nullptr, *S = nullptr, *lambda = nullptr, *mu = nullptr;
@@ -584,10 +585,11 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     vs.n = n_rows[v]; vs.m = n_cols[v]; vs.k = k[v];
     vs.NT = ceil_div(k[v], 16); vs.KP = 16 * vs.NT;
     vs.n_pad = round_up(vs.n, 64); vs.m_pad = round_up(vs.m, 64);
-    // a row pitch that is a multiple of 4 KiB puts every row of a 64-column tile on the same
-    // memory channel; one extra 256-B column block per row spreads a tile over all channels
-    auto pitch = [&](int cols_pad) { return (cols_pad % 1024 == 0 && !o.no_pitch_pad) ? cols_pad + 64 : cols_pad; };
-    vs.ldx = pitch(vs.m_pad); vs.ldxt = pitch(vs.n_pad);
+    // tile-major images: tile t of X32 = columns 64 t .. 64 t + 63 of X as [n_pad][64], contiguous; one extra
+    // 256-B row per tile keeps the tile starts off a common power-of-two stride (memory channels)
+    const size_t pad_rows = o.no_pitch_pad ? 0 : 1;
+    vs.ldx = ((size_t)vs.n_pad + pad_rows) * 64; vs.ldxt = ((size_t)vs.m_pad + pad_rows) * 64;
+    vs.x32_floats = (size_t)(vs.m_pad / 64) * vs.ldx; vs.xt32_floats = (size_t)(vs.n_pad / 64) * vs.ldxt;
     vs.owned = owned ? owned[v] != 0 : true;
     if (!vs.owned) h->all_owned = false;
     else h->last_owned = v;
@@ -688,8 +690,8 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     }
     if ((e = dev_alloc_zero(&vs.mu, (size_t)vs.k)) != hipSuccess) return bail(e, "hipMalloc mu");
     if ((e = dev_alloc_zero(&vs.xnorm2, 1)) != hipSuccess) return bail(e, "hipMalloc xnorm2");
-    if ((e = dev_alloc_zero(&vs.X32, (size_t)vs.n_pad * vs.ldx)) != hipSuccess) return bail(e, "hipMalloc X32");
-    if ((e = dev_alloc_zero(&vs.Xt32, (size_t)vs.m_pad * vs.ldxt)) != hipSuccess) return bail(e, "hipMalloc Xt32");
+    if ((e = dev_alloc_zero(&vs.X32, vs.x32_floats)) != hipSuccess) return bail(e, "hipMalloc X32");
+    if ((e = dev_alloc_zero(&vs.Xt32, vs.xt32_floats)) != hipSuccess) return bail(e, "hipMalloc Xt32");
     if ((e = dev_alloc_zero(&vs.F32, (size_t)vs.n_pad * 64)) != hipSuccess) return bail(e, "hipMalloc F32");
     if ((e = dev_alloc_zero(&vs.G32, (size_t)vs.m_pad * 64)) != hipSuccess) return bail(e, "hipMalloc G32");
     if ((e = dev_alloc_zero(&vs.T32, (size_t)vs.m_pad * 64)) != hipSuccess) return bail(e, "hipMalloc T32");
@@ -741,7 +743,7 @@ namespace {
 // matrix_normalisation (R/utils.r:20-27, 86-88) run on the device, fused into the conversion.
 // Source of the staging image: the host matrix x, or (x == NULL) a pseudo-random permutation of the
 // entries of another view's device copy (shuffle_src, see resnmtf_shuffle_view).
-struct ShuffleSrc { const float* X32; int ldx; unsigned long long seed; const int* rows; const int* cols; };   // rows != NULL: sub-sample
+struct ShuffleSrc { const float* X32; size_t ldx; unsigned long long seed; const int* rows; const int* cols; };   // rows != NULL: sub-sample
 int upload_view(resnmtf_handle* h, int v, const double* x, bool raw, int* was_negative, const ShuffleSrc* shuffle_src = nullptr) {
   if (int rc = check_view(h, v)) return rc;
   if (!x && !shuffle_src) return h->fail(RESNMTF_ERR_INVALID, "x is NULL");
@@ -773,8 +775,8 @@ int upload_view(resnmtf_handle* h, int v, const double* x, bool raw, int* was_ne
                          shuffle_src->ldx, vs.n, vs.m, shuffle_src->seed, staging);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemsetAsync(vs.X32, 0, (size_t)vs.n_pad * vs.ldx * sizeof(float), h->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(vs.Xt32, 0, (size_t)vs.m_pad * vs.ldxt * sizeof(float), h->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(vs.X32, 0, vs.x32_floats * sizeof(float), h->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(vs.Xt32, 0, vs.xt32_floats * sizeof(float), h->stream);
   if (e == hipSuccess && raw) e = hipMemsetAsync(neg, 0, sizeof(double), h->stream);
   if (e == hipSuccess) {
     if (raw) hipLaunchKernelGGL(column_stats_kernel, dim3(vs.m), dim3(256), 0, h->stream, staging, vs.n, vs.m, shift, colsum, neg);
@@ -822,8 +824,8 @@ int resnmtf_copy_view(resnmtf_handle* dst, int v, resnmtf_handle* src, int v_src
   if (int rc = sync_both(dst)) return rc;
   // same shape and options decide the same pitches; guard anyway
   if (a.ldx != b.ldx || a.ldxt != b.ldxt) return dst->fail(RESNMTF_ERR_INVALID, "views differ in device layout (no_pitch_pad)");
-  HIP_TRY(dst, hipMemcpyAsync(a.X32, b.X32, (size_t)a.n_pad * a.ldx * sizeof(float), hipMemcpyDeviceToDevice, dst->stream));
-  HIP_TRY(dst, hipMemcpyAsync(a.Xt32, b.Xt32, (size_t)a.m_pad * a.ldxt * sizeof(float), hipMemcpyDeviceToDevice, dst->stream));
+  HIP_TRY(dst, hipMemcpyAsync(a.X32, b.X32, a.x32_floats * sizeof(float), hipMemcpyDeviceToDevice, dst->stream));
+  HIP_TRY(dst, hipMemcpyAsync(a.Xt32, b.Xt32, a.xt32_floats * sizeof(float), hipMemcpyDeviceToDevice, dst->stream));
   HIP_TRY(dst, hipMemcpyAsync(a.xnorm2, b.xnorm2, sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
   HIP_TRY(dst, hipStreamSynchronize(dst->stream));
   a.has_x = true;
@@ -869,10 +871,10 @@ int resnmtf_get_view(resnmtf_handle* h, int v, double* x) {
   if (!vs.owned || !vs.has_x) return h->fail(RESNMTF_ERR_STATE, "no data on this handle for the view");
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
   if (int rc = sync_both(h)) return rc;
-  std::vector<float> t((size_t)vs.m * vs.ldxt);          // Xt32 rows = columns of X: already R's column-major order
+  std::vector<float> t(vs.xt32_floats);                  // Xt32(c, r) = X[r][c], tile-major over r
   HIP_TRY(h, hipMemcpy(t.data(), vs.Xt32, t.size() * sizeof(float), hipMemcpyDeviceToHost));
   for (int c = 0; c < vs.m; ++c)
-    for (int r = 0; r < vs.n; ++r) x[(size_t)c * vs.n + r] = (double)t[(size_t)c * vs.ldxt + r];
+    for (int r = 0; r < vs.n; ++r) x[(size_t)c * vs.n + r] = (double)t[xidx(c, r, vs.ldxt)];
   return RESNMTF_OK;
 }
 
@@ -1139,9 +1141,9 @@ int resnmtf_init_svd(resnmtf_handle* h, int v, unsigned long long seed, double s
     sc.own_pm = true;
   }
   PassArgs xg{}, xt{};
-  xg.A = vs.Xt32; xg.lda = vs.ldxt; xg.ntiles = vs.n_pad / 64; xg.B = vs.G32; xg.ldb = 64; xg.P = sc.Pn;
+  xg.A = vs.Xt32; xg.lda = 64; xg.tile_stride = vs.ldxt; xg.ntiles = vs.n_pad / 64; xg.B = vs.G32; xg.ldb = 64; xg.P = sc.Pn;
   xg.cols_pad = vs.n_pad; xg.rows_pad = vs.m_pad; xg.rows_per_split = vs.rps_xg; xg.nsplit = vs.nsplit_xg; xg.ctl = h->ctl;
-  xt.A = vs.X32; xt.lda = vs.ldx; xt.ntiles = vs.m_pad / 64; xt.B = vs.F32; xt.ldb = 64; xt.P = sc.Pm;
+  xt.A = vs.X32; xt.lda = 64; xt.tile_stride = vs.ldx; xt.ntiles = vs.m_pad / 64; xt.B = vs.F32; xt.ldb = 64; xt.P = sc.Pm;
   xt.cols_pad = vs.m_pad; xt.rows_pad = vs.n_pad; xt.rows_per_split = vs.rps_xtf; xt.nsplit = vs.nsplit_xtf; xt.ctl = h->ctl;
 
   // Omega: m x L standard normal (host generator: the reference's RNG is not reproducible anyway)
@@ -1323,14 +1325,14 @@ static int build_args(resnmtf_handle* h) {
     // --- streaming passes
     PassArgs& xg = vs.passXG;
     xg = PassArgs{};
-    xg.A = vs.Xt32; xg.lda = vs.ldxt; xg.ntiles = vs.n_pad / 64; xg.B = vs.G32; xg.ldb = vs.kk_mode == 0 ? vs.KP : 64; xg.P = vs.Pxg;
+    xg.A = vs.Xt32; xg.lda = 64; xg.tile_stride = vs.ldxt; xg.ntiles = vs.n_pad / 64; xg.B = vs.G32; xg.ldb = vs.kk_mode == 0 ? vs.KP : 64; xg.P = vs.Pxg;
     xg.cols_pad = vs.n_pad; xg.rows_pad = vs.m_pad; xg.rows_per_split = vs.rps_xg; xg.nsplit = vs.nsplit_xg;
     xg.aux[0] = vs.G32; xg.aux[1] = vs.T32; xg.aux[2] = nullptr; xg.naux = 3;     // G^T G, T^T G, colSums(G)
     xg.Paux = vs.Paux_xg; xg.rows_per_split_aux = vs.rpsaux_xg; xg.nsplit_aux = vs.nsaux_xg; xg.aux_cnt = vs.cnt_xg;
     xg.ctl = h->ctl;
     PassArgs& xt = vs.passXtF;
     xt = PassArgs{};
-    xt.A = vs.X32; xt.lda = vs.ldx; xt.ntiles = vs.m_pad / 64; xt.B = vs.F32; xt.ldb = vs.kk_mode == 0 ? vs.KP : 64; xt.P = vs.Pxtf;
+    xt.A = vs.X32; xt.lda = 64; xt.tile_stride = vs.ldx; xt.ntiles = vs.m_pad / 64; xt.B = vs.F32; xt.ldb = vs.kk_mode == 0 ? vs.KP : 64; xt.P = vs.Pxtf;
     xt.cols_pad = vs.m_pad; xt.rows_pad = vs.n_pad; xt.rows_per_split = vs.rps_xtf; xt.nsplit = vs.nsplit_xtf;
     xt.aux[0] = vs.F32; xt.aux[1] = nullptr; xt.naux = 2;                          // F^T F, colSums(F)
     xt.Paux = vs.Paux_xtf; xt.rows_per_split_aux = vs.rpsaux_xtf; xt.nsplit_aux = vs.nsaux_xtf; xt.aux_cnt = vs.cnt_xtf;
