@@ -62,6 +62,36 @@ def cpu_baseline(prob, warm: int = 3, timed: int = 20) -> dict:
                       f"{threads} threads; R unavailable on the box"}
 
 
+def pass_roofline(make_engine, steps: int, warmup: int) -> dict:
+    """Roofline leg: `steps` sweeps of one c2-shaped view, eager, every streaming-pass launch timed by HIP events
+    attached to the dispatch on the library's stream (dominant kernels: the X.G and Xt.F streaming passes)."""
+    eng2, _ = make_engine(time_kernels=True)
+    if warmup > 0:
+        eng2.run(min(warmup, 20))
+    eng2.pass_timings(reset=True)
+    eng2.run(steps)
+    t = eng2.pass_timings()
+    eng2.close()
+    launches = t["xg_launches"] + t["xtf_launches"]
+    pass_ms = (t["xg_ms_total"] + t["xtf_ms_total"]) / max(launches, 1)
+    bytes_per_launch = (t["xg_bytes"] * t["xg_launches"] + t["xtf_bytes"] * t["xtf_launches"]) / max(launches, 1)
+    achieved = bytes_per_launch / (pass_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "pass_kernel<NT,NW,UNROLL,IS_XG,MODE_A> (X.G and Xt.F streaming passes, same pass_body)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_us": round(pass_ms * 1e3, 3), "launches": int(launches),
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "xg_avg_us": round(t["xg_ms_total"] / max(t["xg_launches"], 1) * 1e3, 3),
+                "xtf_avg_us": round(t["xtf_ms_total"] / max(t["xtf_launches"], 1) * 1e3, 3),
+                "mfma_tflops": round((t["xg_flops"] + t["xtf_flops"]) / 2 / (pass_ms * 1e-3) / 1e12, 2)}
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(traffic_file):          # HBM bytes per launch from the PMC passes (profiles/README.md)
+        try:
+            roofline["traffic"] = json.load(open(traffic_file)).get("atb_pass_kernel_bytes_per_launch")
+        except Exception:
+            pass
+    return roofline
+
+
 def run_single(args) -> dict:
     import torch
     from resnmtf_amd import synth
@@ -93,32 +123,7 @@ def run_single(args) -> dict:
     assert len(errs) == args.steps and np.isfinite(errs).all()
     eng.close()
 
-    # roofline leg: the same K sweeps, eager, every streaming-pass launch timed by HIP events attached
-    # to the dispatch on the library's stream (dominant kernels: the X.G and Xt.F streaming passes)
-    eng2, _ = make_engine(time_kernels=True)
-    if args.warmup > 0:
-        eng2.run(min(args.warmup, 20))
-    eng2.pass_timings(reset=True)
-    eng2.run(args.steps)
-    t = eng2.pass_timings()
-    eng2.close()
-    launches = t["xg_launches"] + t["xtf_launches"]
-    pass_ms = (t["xg_ms_total"] + t["xtf_ms_total"]) / max(launches, 1)
-    bytes_per_launch = (t["xg_bytes"] * t["xg_launches"] + t["xtf_bytes"] * t["xtf_launches"]) / max(launches, 1)
-    achieved = bytes_per_launch / (pass_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "pass_kernel<NT,NW,UNROLL,IS_XG,MODE_A> (X.G and Xt.F streaming passes, same pass_body)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "avg_launch_us": round(pass_ms * 1e3, 3), "launches": int(launches),
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-                "xg_avg_us": round(t["xg_ms_total"] / max(t["xg_launches"], 1) * 1e3, 3),
-                "xtf_avg_us": round(t["xtf_ms_total"] / max(t["xtf_launches"], 1) * 1e3, 3),
-                "mfma_tflops": round((t["xg_flops"] + t["xtf_flops"]) / 2 / (pass_ms * 1e-3) / 1e12, 2)}
-    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(traffic_file):          # HBM bytes per launch from the PMC passes (profiles/README.md)
-        try:
-            roofline["traffic"] = json.load(open(traffic_file)).get("atb_pass_kernel_bytes_per_launch")
-        except Exception:
-            pass
+    roofline = pass_roofline(make_engine, args.steps, args.warmup)
 
     cpu = cpu_baseline(prob) if not args.no_cpu_baseline else None
     value = args.steps * 1 / dt
@@ -182,6 +187,23 @@ def run_sharded(args) -> dict:
     replicated = any(drv.replicated)
     allgather = drv._allgather_blocks
     drv.close()
+    roofline = None
+    if rank == 0:      # the same streaming passes (rank 0's own view, same shape) timed per launch while the others wait
+        from resnmtf_amd.engine import Engine
+
+        def make_engine(**kw):
+            e = Engine([n], [m], [k], device_id=local_rank, **kw)
+            e.set_view(0, prob.data[0])
+            e.set_restrictions(None, None, None)
+            e.set_factors(0, prob.init_f[0], prob.init_s[0], prob.init_g[0])
+            return e, 0.0
+        try:
+            roofline = pass_roofline(make_engine, min(args.steps, 200), args.warmup)
+            roofline["note"] = "rank 0's view alone (uncoupled), after the timed region"
+        except Exception as exc:      # never lose the bench line to the extra leg
+            roofline = None
+            print(f"[bench] roofline leg failed: {exc}", file=sys.stderr)
+    dist.barrier()
     dist.destroy_process_group()
     if rank != 0:
         return {}
@@ -195,7 +217,7 @@ def run_sharded(args) -> dict:
                                   if replicated else "F exchanged by ordered RCCL broadcasts, ") + "Gauss-Seidel order kept exactly",
                    "n_views": n_views, "rows": n, "cols": m, "k": k,
                    "final_error": float(errs[-1]) if len(errs) else None},
-        "roofline": None, "cpu_baseline": None,
+        "roofline": roofline, "cpu_baseline": None,
     }
 
 
