@@ -59,7 +59,8 @@ enum {
                              others), in view order; `v` only has to be a valid view.  F_w' does not read G or S of this
                              sweep, so hoisting the F updates of a sweep in front of its PHASE_G calls changes nothing.
                              One launch (f_chain_kernel) when k <= 16, the views have equal row counts, share their rows in
-                             the same order and at most one of them is owned; one launch per view otherwise */,
+                             the same order and at most four of them are owned; one launch per view otherwise.  resnmtf_run
+                             hoists the F updates of a sweep the same way when that launch applies */,
   RESNMTF_PHASE_LOCAL_SWEEP = 4 /* RESNMTF_PHASE_F_ALL followed by RESNMTF_PHASE_G of every owned view: everything a rank
                              does between two exchanges of the F blocks when no G or S crosses ranks, in one call */
 };

@@ -225,9 +225,10 @@ hipError_t set_all_attrs() {
   TRY_ATTR(set_smem_attrs<48>()); TRY_ATTR(set_smem_attrs<64>());
   TRY_ATTR((set_pass_attr<1, 4, 8>())); TRY_ATTR((set_pass_attr<1, 8, 8>())); TRY_ATTR((set_pass_attr<1, 8, 4>())); TRY_ATTR((set_pass_attr<1, 16, 8>()));
   TRY_ATTR((set_pass_attr<2, 8, 4>())); TRY_ATTR((set_pass_attr<3, 8, 4>())); TRY_ATTR((set_pass_attr<4, 8, 4>()));
-  TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&f_chain_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f_chain_smem_bytes<2>()));
-  TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&f_chain_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f_chain_smem_bytes<4>()));
-  TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&f_chain_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f_chain_smem_bytes<8>()));
+#define CHAIN_ATTR(NVB, PFV) TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&f_chain_kernel<NVB, PFV>), \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)f_chain_smem_bytes<NVB>()))
+  CHAIN_ATTR(2, 1); CHAIN_ATTR(4, 1); CHAIN_ATTR(8, 1); CHAIN_ATTR(2, 4); CHAIN_ATTR(4, 4); CHAIN_ATTR(8, 4);
+#undef CHAIN_ATTR
 #undef TRY_ATTR
   return hipSuccess;
 }
@@ -310,9 +311,11 @@ template <int NVB>
 ChainArgs<NVB> narrow_chain(const ChainArgs<8>& c) {
   ChainArgs<NVB> a{};
   a.len = c.len; a.k = c.k; a.n_views = c.n_views; a.rows_per_block = c.rows_per_block;
-  a.emit = c.emit; a.W32e = c.W32e; a.parte = c.parte; a.restricted = c.restricted;
+  a.n_emit = c.n_emit; a.restricted = c.restricted; a.ctl = c.ctl; a.check_done = c.check_done; a.pstride = c.pstride;
+  for (int e = 0; e < 4; ++e) { a.W32e[e] = c.W32e[e]; a.parte[e] = c.parte[e]; }
   for (int v = 0; v < NVB; ++v) {
-    a.W[v] = c.W[v]; a.U[v] = c.U[v]; a.Ma[v] = c.Ma[v]; a.Md[v] = c.Md[v]; a.lm[v] = c.lm[v];
+    a.emit_slot[v] = c.emit_slot[v];
+    a.W[v] = c.W[v]; a.U[v] = c.U[v]; a.nsplit[v] = c.nsplit[v]; a.Ma[v] = c.Ma[v]; a.Md[v] = c.Md[v]; a.lm[v] = c.lm[v];
     a.sigma[v] = c.sigma[v]; a.n_other[v] = c.n_other[v]; a.cmask[v] = c.cmask[v];
     for (int w = 0; w < NVB; ++w) a.weight[v][w] = c.weight[v][w];
   }
@@ -352,22 +355,29 @@ void launch_update(resnmtf_handle* h, const ViewState& v, int kind, bool check_d
 }
 
 // RESNMTF_PHASE_F_ALL: update_f of every view in view order (one launch when the chain is eligible)
-void enqueue_phase_f_all(resnmtf_handle* h) {
+void enqueue_phase_f_all(resnmtf_handle* h, bool checked = false) {
   if (h->chain_views > 0) {
+    h->chain.check_done = checked ? 1 : 0;
     const size_t smem = h->chain_views <= 2 ? f_chain_smem_bytes<2>() : h->chain_views <= 4 ? f_chain_smem_bytes<4>() : f_chain_smem_bytes<8>();
+    bool one_slab = true;
+    for (int v = 0; v < h->chain_views; ++v) one_slab = one_slab && h->chain.nsplit[v] == 1;
+#define LAUNCH_CHAIN(NVB, ARGS)                                                                                         \
+    if (one_slab) hipLaunchKernelGGL((f_chain_kernel<NVB, 1>), dim3(h->chain_blocks), dim3(512), smem, h->stream, ARGS);  \
+    else hipLaunchKernelGGL((f_chain_kernel<NVB, 4>), dim3(h->chain_blocks), dim3(512), smem, h->stream, ARGS)
     if (h->chain_views <= 2) {
       ChainArgs<2> a = narrow_chain<2>(h->chain);
-      hipLaunchKernelGGL(f_chain_kernel<2>, dim3(h->chain_blocks), dim3(512), smem, h->stream, a);
+      LAUNCH_CHAIN(2, a);
     } else if (h->chain_views <= 4) {
       ChainArgs<4> a = narrow_chain<4>(h->chain);
-      hipLaunchKernelGGL(f_chain_kernel<4>, dim3(h->chain_blocks), dim3(512), smem, h->stream, a);
+      LAUNCH_CHAIN(4, a);
     } else {
-      hipLaunchKernelGGL(f_chain_kernel<8>, dim3(h->chain_blocks), dim3(512), smem, h->stream, h->chain);
+      LAUNCH_CHAIN(8, h->chain);
     }
+#undef LAUNCH_CHAIN
     return;
   }
   for (const auto& v : h->views)
-    if (v.owned || v.f_replica) launch_update(h, v, 0, false);
+    if (v.owned || v.f_replica) launch_update(h, v, 0, checked);
 }
 
 // ---- the phases of one view (see the header comment)
@@ -395,9 +405,13 @@ void enqueue_prologue(resnmtf_handle* h, const ViewState& v) {
 
 void enqueue_sweep(resnmtf_handle* h, double tol) {
   const bool checked = tol >= 0.0;
+  // F_w' reads neither G nor S of the same sweep: when the fused chain applies (several k <= 16 views sharing
+  // their rows in the same order) every F update of the sweep runs first, in one launch
+  const bool hoist = h->chain_views > 0 && h->all_owned;
+  if (hoist) enqueue_phase_f_all(h, checked);
   for (const auto& v : h->views) {
     if (!v.owned) continue;
-    enqueue_phase_f(h, v, checked);
+    if (!hoist) enqueue_phase_f(h, v, checked);
     enqueue_phase_g(h, v, tol, checked);
   }
 }
@@ -1248,33 +1262,38 @@ int resnmtf_set_shared_cols(resnmtf_handle* h, int v, int w, int count, const in
 
 // RESNMTF_PHASE_F_ALL in one launch (f_chain_kernel): every view holds the inputs of its F update here
 // (owned, or an F replica), k <= 16 in hand-off mode A, equal row counts and row blocking, every coupling
-// through identity row maps, at most one owned view, at most 8 views.  Otherwise one launch per view.
+// through identity row maps, at most four owned views, at most 8 views.  Otherwise one launch per view.
 static void build_chain(resnmtf_handle* h) {
   h->chain_views = 0;
   const int V = h->V;
   if (V < 2 || V > 8 || h->opt.no_f_chain) return;
   const ViewState& v0 = h->views[0];
-  int n_owned = 0, emit = -1;
+  int n_owned = 0;
   for (int v = 0; v < V; ++v) {
     const ViewState& vs = h->views[v];
     if (!vs.owned && !vs.f_replica) return;
     if (vs.KP != 16 || vs.kk_mode != 0 || vs.n != v0.n || vs.k != v0.k || vs.rpbF != v0.rpbF || vs.nblkF != v0.nblkF) return;
-    if (!vs.Usum && vs.nsplit_xg != 1) return;              // the kernel reads ONE product slab per view
-    if (vs.owned) { ++n_owned; emit = v; }
+    if (vs.argF.nsplit > 4 || vs.argF.cols_pad != v0.argF.cols_pad) return;     // raw split slabs the kernel keeps per view
+    if (vs.owned) ++n_owned;
     for (int c = 0; c < vs.argF.n_couple; ++c)
       if (vs.argF.couple[c].map) return;                    // permuted shared rows: rows of different workgroups
   }
-  if (n_owned > 1) return;
+  if (n_owned > 4) return;
   ChainArgs<8>& a = h->chain;
   a = ChainArgs<8>{};
   a.len = v0.n; a.k = v0.k; a.n_views = V; a.rows_per_block = v0.rpbF;
-  a.emit = emit;
-  a.W32e = emit >= 0 ? h->views[emit].F32 : nullptr;
-  a.parte = emit >= 0 ? h->views[emit].partF : nullptr;
+  a.ctl = h->ctl;
+  a.pstride = (size_t)v0.argF.cols_pad * 16;
+  for (int v = 0; v < 8; ++v) a.emit_slot[v] = -1;
   for (int v = 0; v < V; ++v) {
     const ViewState& vs = h->views[v];
     const UpdateArgs& f = vs.argF;
-    a.W[v] = vs.F; a.U[v] = f.P; a.Ma[v] = vs.Ma_F; a.Md[v] = vs.Md_F; a.lm[v] = vs.lambda;
+    if (vs.owned) {
+      a.emit_slot[v] = a.n_emit;
+      a.W32e[a.n_emit] = vs.F32; a.parte[a.n_emit] = vs.partF;
+      ++a.n_emit;
+    }
+    a.W[v] = vs.F; a.U[v] = f.P; a.nsplit[v] = f.nsplit; a.Ma[v] = vs.Ma_F; a.Md[v] = vs.Md_F; a.lm[v] = vs.lambda;
     a.sigma[v] = f.sigma;
     a.n_other[v] = (double)vs.n;
     if (f.restricted) a.restricted |= 1u << v;

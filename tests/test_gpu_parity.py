@@ -399,3 +399,29 @@ def test_device_svd_init_thin_views(shape, k):
     np.testing.assert_allclose(d, d_ref, rtol=1e-5, atol=1e-7 * d_ref[0])
     strong = d_ref > 1e-3 * d_ref[0]
     assert rel_fro(f0[:, strong], rf[0][:, strong]) < 1e-4 and rel_fro(g0[:, strong], rg[0][:, strong]) < 1e-4
+
+
+@pytest.mark.parametrize("shapes,k,kw", [
+    ([(600, 200), (600, 150)], 16, {"phi": 200.0}),                     # 2 views, X.G in 4 splits
+    ([(640, 128)] * 3, 7, {"phi": 1.5, "xi": 0.2}),                     # 3 views -> the 4-view instantiation
+    ([(512, 192)] * 5, 12, {"phi": 0.7}),                               # 5 views -> the 8-view instantiation, fall-back emit (> 4 owned)
+    ([(300, 128), (300, 128)], 5, {}),                                  # uncoupled views: NaN -> 1 branch inside the chain
+])
+def test_hoisted_fused_f_chain_equals_per_view_launches(shapes, k, kw):
+    """resnmtf_run hoists the F updates of a sweep into one launch (f_chain_kernel) when the views share their rows
+    in the same order and k <= 16.  Same arithmetic as one factor_update_kernel launch per view in the
+    reference's order: results must agree to rounding of nothing (bitwise), fixed sweeps and convergence mode."""
+    prob = synth.make_problem(shapes, k, **kw)
+    a = run_hip(prob, n_iters=40)
+    b = run_hip(prob, n_iters=40, no_f_chain=True)
+    assert np.array_equal(a["All_Error"], b["All_Error"])
+    for v in range(len(shapes)):
+        assert np.array_equal(a["output_f"][v], b["output_f"][v])
+        assert np.array_equal(a["output_g"][v], b["output_g"][v])
+        assert np.array_equal(a["output_s"][v], b["output_s"][v])
+    ref = run_oracle(prob, n_iters=40)
+    check_against(a, ref["output_f"], ref["output_s"], ref["output_g"], ref["row_clusters"], ref["col_clusters"],
+                  ref["All_Error"])
+    c = run_hip(prob, n_iters=None, max_iters=400)
+    d = run_hip(prob, n_iters=None, max_iters=400, no_f_chain=True)
+    assert len(c["All_Error"]) == len(d["All_Error"]) and np.array_equal(c["All_Error"], d["All_Error"])
