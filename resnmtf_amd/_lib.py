@@ -32,7 +32,7 @@ class Options(C.Structure):
         ("time_kernels", C.c_int), ("pass_waves", C.c_int), ("pass_splits_xg", C.c_int),
         ("pass_splits_xtf", C.c_int), ("pass_lds_pad_kb", C.c_int), ("update_blocks", C.c_int),
         ("no_pitch_pad", C.c_int), ("kk_mode", C.c_int), ("bf16_split", C.c_int), ("replicate_f", C.c_int),
-        ("no_f_chain", C.c_int),
+        ("no_f_chain", C.c_int), ("x_half", C.c_int), ("half_unroll", C.c_int),
     ]
 
 

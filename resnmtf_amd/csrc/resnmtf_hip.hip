@@ -46,6 +46,11 @@ struct ViewState {
   int n_pad = 0, m_pad = 0;
   size_t ldx = 0, ldxt = 0;      // TILE strides of X32 / Xt32 (floats): tile t (64 columns) is a contiguous [rows_pad][64] block
   size_t x32_floats = 0, xt32_floats = 0;
+  // fp16 passes (resnmtf_options.x_half, k <= 16): K-packed fp16 images of X / X^T, their tile strides (halves), scale
+  bool half = false;
+  _Float16 *X16 = nullptr, *Xt16 = nullptr;
+  size_t ld16x = 0, ld16xt = 0, x16_halves = 0, xt16_halves = 0;
+  float xscale = 1.f;
   float *X32 = nullptr, *Xt32 = nullptr;
   double* xnorm2 = nullptr;
   double *F = nullptr, *G = nullptr, *S = nullptr, *lambda = nullptr, *mu = nullptr;
@@ -131,7 +136,7 @@ hipError_t dev_alloc_zero(T** p, size_t count) {
 
 void free_view(ViewState& v) {
   if (v.fblk) { v.fblk = nullptr; v.Usum = nullptr; v.Ma_F = nullptr; v.Md_F = nullptr; v.lambda = nullptr; }   // arena slices
-  void* ptrs[] = {v.X32, v.Xt32, v.xnorm2, v.F, v.G, v.S, v.lambda, v.mu, v.F32, v.G32, v.T32, v.Pxg, v.Pxtf,
+  void* ptrs[] = {v.X16, v.Xt16, v.X32, v.Xt32, v.xnorm2, v.F, v.G, v.S, v.lambda, v.mu, v.F32, v.G32, v.T32, v.Pxg, v.Pxtf,
                   v.Paux_xg, v.Paux_xtf, v.cnt_xg, v.cnt_xtf, v.partF, v.partG, v.FtF, v.FtFS, v.cF, v.Ma_F, v.Md_F, v.Ma_G, v.Md_G};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -259,6 +264,27 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
   // MFMA form of the main tiles (resnmtf_options.bf16_split): k <= 16 always the f32 MFMA; k > 16: 0 =
   // three-piece bf16 split (f32-grade, default), 1 = two-piece (16-bit mantissa, fastest), 2 = plain f32
   const int split = v.NT < 2 ? 0 : (h->opt.bf16_split == 1 ? 2 : (h->opt.bf16_split == 2 ? 0 : 3));
+  if (v.half) {       // fp16 image of X: the run-time scale (set at upload) is taken out in the slab store
+    a.out_scale = 1.f / (v.xscale * RESNMTF_B16_SCALE);
+    const int un = h->opt.half_unroll == 2 ? 2 : (h->opt.half_unroll == 6 ? 6 : (h->opt.half_unroll == 3 ? 3 : 4));
+#define LAUNCH_HALF(UV, XG)                                                                                             \
+    if (timed) hipExtLaunchKernelGGL((pass_half_kernel<UV, XG>), grid, block, smem, h->stream, ev0, ev1, 0, a, kf, ks);  \
+    else hipLaunchKernelGGL((pass_half_kernel<UV, XG>), grid, block, smem, h->stream, a, kf, ks)
+#define LAUNCH_HALF_U(UV) if (xg) { LAUNCH_HALF(UV, true); } else { LAUNCH_HALF(UV, false); }
+    switch (un) {
+      case 2: LAUNCH_HALF_U(2); break;
+      case 3: LAUNCH_HALF_U(3); break;
+      case 6: LAUNCH_HALF_U(6); break;
+      default: LAUNCH_HALF_U(4); break;
+    }
+#undef LAUNCH_HALF_U
+#undef LAUNCH_HALF
+    if (timed) {
+      h->ev_kind[h->ev_used / 2] = xg ? 0 : 1;
+      h->ev_used += 2;
+    }
+    return;
+  }
 #define LAUNCH_PASS_B(NTV, NWV, UV, XG, MA, SP)                                                                              \
   if (timed) hipExtLaunchKernelGGL((pass_kernel<NTV, NWV, UV, XG, MA, SP>), grid, block, smem, h->stream, ev0, ev1, 0, a, kf, ks); \
   else hipLaunchKernelGGL((pass_kernel<NTV, NWV, UV, XG, MA, SP>), grid, block, smem, h->stream, a, kf, ks)
@@ -312,6 +338,7 @@ ChainArgs<NVB> narrow_chain(const ChainArgs<8>& c) {
   ChainArgs<NVB> a{};
   a.len = c.len; a.k = c.k; a.n_views = c.n_views; a.rows_per_block = c.rows_per_block;
   a.n_emit = c.n_emit; a.restricted = c.restricted; a.ctl = c.ctl; a.check_done = c.check_done; a.pstride = c.pstride;
+  a.kpack32 = c.kpack32;
   for (int e = 0; e < 4; ++e) { a.W32e[e] = c.W32e[e]; a.parte[e] = c.parte[e]; }
   for (int v = 0; v < NVB; ++v) {
     a.emit_slot[v] = c.emit_slot[v];
@@ -706,6 +733,13 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     if ((e = dev_alloc_zero(&vs.xnorm2, 1)) != hipSuccess) return bail(e, "hipMalloc xnorm2");
     if ((e = dev_alloc_zero(&vs.X32, vs.x32_floats)) != hipSuccess) return bail(e, "hipMalloc X32");
     if ((e = dev_alloc_zero(&vs.Xt32, vs.xt32_floats)) != hipSuccess) return bail(e, "hipMalloc Xt32");
+    vs.half = o.x_half == 1 && vs.NT == 1 && vs.kk_mode == 0 && vs.nw_xg == 8 && vs.nw_xtf == 8;
+    if (vs.half) {      // one spare row group per tile keeps the tile starts off a common power-of-two stride
+      vs.ld16x = ((size_t)vs.n_pad + 4) * 64; vs.ld16xt = ((size_t)vs.m_pad + 4) * 64;
+      vs.x16_halves = (size_t)(vs.m_pad / 64) * vs.ld16x; vs.xt16_halves = (size_t)(vs.n_pad / 64) * vs.ld16xt;
+      if ((e = dev_alloc_zero(&vs.X16, vs.x16_halves)) != hipSuccess) return bail(e, "hipMalloc X16");
+      if ((e = dev_alloc_zero(&vs.Xt16, vs.xt16_halves)) != hipSuccess) return bail(e, "hipMalloc Xt16");
+    }
     if ((e = dev_alloc_zero(&vs.F32, (size_t)vs.n_pad * 64)) != hipSuccess) return bail(e, "hipMalloc F32");
     if ((e = dev_alloc_zero(&vs.G32, (size_t)vs.m_pad * 64)) != hipSuccess) return bail(e, "hipMalloc G32");
     if ((e = dev_alloc_zero(&vs.T32, (size_t)vs.m_pad * 64)) != hipSuccess) return bail(e, "hipMalloc T32");
@@ -757,6 +791,32 @@ namespace {
 // matrix_normalisation (R/utils.r:20-27, 86-88) run on the device, fused into the conversion.
 // Source of the staging image: the host matrix x, or (x == NULL) a pseudo-random permutation of the
 // entries of another view's device copy (shuffle_src, see resnmtf_shuffle_view).
+// fp16 images of an uploaded view: per-view power-of-two scale that puts the largest entry near 2^14
+int build_half_images(resnmtf_handle* h, ViewState& vs) {
+  unsigned int* dmax = nullptr;
+  HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&dmax), sizeof(unsigned int)));
+  hipError_t e = hipMemsetAsync(dmax, 0, sizeof(unsigned int), h->stream);
+  unsigned int bits = 0;
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(max_entry_kernel, dim3(1024), dim3(256), 0, h->stream, vs.X32, vs.x32_floats, dmax);
+    e = hipMemcpyAsync(&bits, dmax, sizeof(bits), hipMemcpyDeviceToHost, h->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(dmax);
+  if (e != hipSuccess) return h->fail_hip("half images (max)", e);
+  float mx;
+  std::memcpy(&mx, &bits, sizeof(mx));
+  int ex = 0;
+  vs.xscale = 1.f;
+  if (mx > 0.f && std::isfinite(mx)) { (void)std::frexp(mx, &ex); vs.xscale = std::ldexp(1.f, 14 - ex); }   // max * scale in [2^13, 2^14)
+  hipLaunchKernelGGL(pack_half_kernel, dim3((unsigned)(((size_t)(vs.n_pad / 4) * 64 * (vs.m_pad / 64) + 255) / 256)), dim3(256), 0,
+                     h->stream, vs.X32, vs.ldx, vs.n_pad, vs.m_pad / 64, vs.xscale, vs.X16, vs.ld16x);
+  hipLaunchKernelGGL(pack_half_kernel, dim3((unsigned)(((size_t)(vs.m_pad / 4) * 64 * (vs.n_pad / 64) + 255) / 256)), dim3(256), 0,
+                     h->stream, vs.Xt32, vs.ldxt, vs.m_pad, vs.n_pad / 64, vs.xscale, vs.Xt16, vs.ld16xt);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return RESNMTF_OK;
+}
 struct ShuffleSrc { const float* X32; size_t ldx; unsigned long long seed; const int* rows; const int* cols; };   // rows != NULL: sub-sample
 int upload_view(resnmtf_handle* h, int v, const double* x, bool raw, int* was_negative, const ShuffleSrc* shuffle_src = nullptr) {
   if (int rc = check_view(h, v)) return rc;
@@ -807,6 +867,7 @@ int upload_view(resnmtf_handle* h, int v, const double* x, bool raw, int* was_ne
   if (e != hipSuccess) return h->fail_hip("set_view", e);
   if (was_negative) *was_negative = neg_host;
   vs.has_x = true;
+  if (vs.half) return build_half_images(h, vs);
   return RESNMTF_OK;
 }
 }  // namespace
@@ -843,6 +904,7 @@ int resnmtf_copy_view(resnmtf_handle* dst, int v, resnmtf_handle* src, int v_src
   HIP_TRY(dst, hipMemcpyAsync(a.xnorm2, b.xnorm2, sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
   HIP_TRY(dst, hipStreamSynchronize(dst->stream));
   a.has_x = true;
+  if (a.half) return build_half_images(dst, a);
   return RESNMTF_OK;
 }
 
@@ -923,9 +985,9 @@ int resnmtf_set_factors(resnmtf_handle* h, int v, const double* F, const double*
     HIP_TRY(h, hipMemsetAsync(vs.cnt_xg, 0, 4 * sizeof(int), h->stream));
     HIP_TRY(h, hipMemsetAsync(vs.cnt_xtf, 0, 4 * sizeof(int), h->stream));
     hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(vs.n * vs.k, 256)), dim3(256), 0, h->stream, vs.F, vs.n,
-                       vs.k, vs.F32, vs.kk_mode == 0 ? vs.KP : 64, vs.NT);
+                       vs.k, vs.F32, vs.kk_mode == 0 ? vs.KP : 64, vs.NT, vs.half ? 1 : 0);
     hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(vs.m * vs.k, 256)), dim3(256), 0, h->stream, vs.G, vs.m,
-                       vs.k, vs.G32, vs.kk_mode == 0 ? vs.KP : 64, vs.NT);
+                       vs.k, vs.G32, vs.kk_mode == 0 ? vs.KP : 64, vs.NT, vs.half ? 1 : 0);
     HIP_TRY(h, hipGetLastError());
   }
   HIP_TRY(h, hipStreamSynchronize(h->stream));   // host vectors go out of scope
@@ -1167,7 +1229,7 @@ int resnmtf_init_svd(resnmtf_handle* h, int v, unsigned long long seed, double s
   HIP_TRY(h, hipMemcpyAsync(sc.Zm, omega.data(), omega.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemsetAsync(vs.F32, 0, (size_t)vs.n_pad * 64 * sizeof(float), h->stream));
   HIP_TRY(h, hipMemsetAsync(vs.G32, 0, (size_t)vs.m_pad * 64 * sizeof(float), h->stream));
-  hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(m * L, 256)), dim3(256), 0, h->stream, sc.Zm, m, L, vs.G32, 64, NTi);
+  hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(m * L, 256)), dim3(256), 0, h->stream, sc.Zm, m, L, vs.G32, 64, NTi, 0);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   for (int it = 0; it < n_power; ++it) {
     launch_pass_plain(h, xg, NTi, true);                                                   // Y = X Z
@@ -1272,6 +1334,7 @@ static void build_chain(resnmtf_handle* h) {
   for (int v = 0; v < V; ++v) {
     const ViewState& vs = h->views[v];
     if (!vs.owned && !vs.f_replica) return;
+    if (vs.owned && vs.half != v0.half && v0.owned) return;
     if (vs.KP != 16 || vs.kk_mode != 0 || vs.n != v0.n || vs.k != v0.k || vs.rpbF != v0.rpbF || vs.nblkF != v0.nblkF) return;
     if (vs.argF.nsplit > 4 || vs.argF.cols_pad != v0.argF.cols_pad) return;     // raw split slabs the kernel keeps per view
     if (vs.owned) ++n_owned;
@@ -1284,6 +1347,7 @@ static void build_chain(resnmtf_handle* h) {
   a.len = v0.n; a.k = v0.k; a.n_views = V; a.rows_per_block = v0.rpbF;
   a.ctl = h->ctl;
   a.pstride = (size_t)v0.argF.cols_pad * 16;
+  a.kpack32 = v0.half ? 1 : 0;
   for (int v = 0; v < 8; ++v) a.emit_slot[v] = -1;
   for (int v = 0; v < V; ++v) {
     const ViewState& vs = h->views[v];
@@ -1318,7 +1382,7 @@ static int build_args(resnmtf_handle* h) {
     // --- F update (R/update_steps.r:141-165)
     UpdateArgs& f = vs.argF;
     f = UpdateArgs{};
-    f.len = vs.n; f.k = vs.k; f.W = vs.F; f.W32 = vs.F32; f.ld32 = vs.kk_mode == 0 ? vs.KP : 64;
+    f.len = vs.n; f.k = vs.k; f.W = vs.F; f.W32 = vs.F32; f.ld32 = vs.kk_mode == 0 ? vs.KP : 64; f.kpack32 = vs.half ? 1 : 0;
     f.P = vs.Pxg; f.nsplit = vs.nsplit_xg; f.cols_pad = vs.n_pad;
     if (vs.Usum) { f.P = vs.Usum; f.nsplit = 1; }      // replicate_f: the folded slab of the exchange block
     f.Ma = vs.Ma_F; f.Md = vs.Md_F; f.lm = vs.lambda; f.T32 = nullptr; f.part = vs.partF;
@@ -1346,6 +1410,7 @@ static int build_args(resnmtf_handle* h) {
     xg = PassArgs{};
     xg.A = vs.Xt32; xg.lda = 64; xg.tile_stride = vs.ldxt; xg.ntiles = vs.n_pad / 64; xg.B = vs.G32; xg.ldb = vs.kk_mode == 0 ? vs.KP : 64; xg.P = vs.Pxg;
     xg.cols_pad = vs.n_pad; xg.rows_pad = vs.m_pad; xg.rows_per_split = vs.rps_xg; xg.nsplit = vs.nsplit_xg;
+    xg.A16 = vs.Xt16; xg.tile_stride16 = vs.ld16xt;
     xg.aux[0] = vs.G32; xg.aux[1] = vs.T32; xg.aux[2] = nullptr; xg.naux = 3;     // G^T G, T^T G, colSums(G)
     xg.Paux = vs.Paux_xg; xg.rows_per_split_aux = vs.rpsaux_xg; xg.nsplit_aux = vs.nsaux_xg; xg.aux_cnt = vs.cnt_xg;
     xg.ctl = h->ctl;
@@ -1353,13 +1418,14 @@ static int build_args(resnmtf_handle* h) {
     xt = PassArgs{};
     xt.A = vs.X32; xt.lda = 64; xt.tile_stride = vs.ldx; xt.ntiles = vs.m_pad / 64; xt.B = vs.F32; xt.ldb = vs.kk_mode == 0 ? vs.KP : 64; xt.P = vs.Pxtf;
     xt.cols_pad = vs.m_pad; xt.rows_pad = vs.n_pad; xt.rows_per_split = vs.rps_xtf; xt.nsplit = vs.nsplit_xtf;
+    xt.A16 = vs.X16; xt.tile_stride16 = vs.ld16x;
     xt.aux[0] = vs.F32; xt.aux[1] = nullptr; xt.naux = 2;                          // F^T F, colSums(F)
     xt.Paux = vs.Paux_xtf; xt.rows_per_split_aux = vs.rpsaux_xtf; xt.nsplit_aux = vs.nsaux_xtf; xt.aux_cnt = vs.cnt_xtf;
     xt.ctl = h->ctl;
     // --- G update (R/update_steps.r:180-207); branch on the WHOLE psi matrix (:190)
     UpdateArgs& g = vs.argG;
     g = UpdateArgs{};
-    g.len = vs.m; g.k = vs.k; g.W = vs.G; g.W32 = vs.G32; g.ld32 = vs.kk_mode == 0 ? vs.KP : 64;
+    g.len = vs.m; g.k = vs.k; g.W = vs.G; g.W32 = vs.G32; g.ld32 = vs.kk_mode == 0 ? vs.KP : 64; g.kpack32 = vs.half ? 1 : 0;
     g.P = vs.Pxtf; g.nsplit = vs.nsplit_xtf; g.cols_pad = vs.m_pad;
     g.Ma = vs.Ma_G; g.Md = vs.Md_G; g.lm = vs.mu; g.T32 = vs.T32; g.part = vs.partG;
     g.rows_per_block = vs.rpbG; g.ctl = h->ctl;
@@ -1638,8 +1704,9 @@ int resnmtf_pass_timings(resnmtf_handle* h, resnmtf_pass_timing* out, int reset)
   for (const auto& v : h->views) {
     if (!v.owned) continue;
     const double n = v.n, m = v.m, k = v.k;
-    out->xg_bytes = 4.0 * n * m + 4.0 * (n + m) * k;
-    out->xtf_bytes = 4.0 * n * m + 4.0 * (n + m) * k;
+    const double sx = v.half ? 2.0 : 4.0;          // bytes per element of X as stored
+    out->xg_bytes = sx * n * m + 4.0 * (n + m) * k;
+    out->xtf_bytes = sx * n * m + 4.0 * (n + m) * k;
     out->xg_flops = 2.0 * n * m * k;
     out->xtf_flops = 2.0 * n * m * k;
     break;

@@ -40,7 +40,8 @@ class Engine:
                  use_graph: bool = True, check_every: int = 32, target_workgroups: int = 0,
                  time_kernels: bool = False, pass_waves: int = 0, pass_splits_xg: int = 0,
                  pass_splits_xtf: int = 0, pass_lds_pad_kb: int = 0, update_blocks: int = 0, no_pitch_pad: bool = False,
-                 kk_mode: int = 0, bf16_split: int = 0, replicate_f: bool = False, no_f_chain: bool = False):
+                 kk_mode: int = 0, bf16_split: int = 0, replicate_f: bool = False, no_f_chain: bool = False,
+                 x_half: int = 0, half_unroll: int = 0):
         self._lib = _lib.load()
         self.n_views = len(n_rows)
         self.n_rows = [int(x) for x in n_rows]
@@ -65,6 +66,8 @@ class Engine:
         opts.bf16_split = int(bf16_split)
         opts.replicate_f = 1 if replicate_f else 0
         opts.no_f_chain = 1 if no_f_chain else 0
+        opts.x_half = int(x_half)
+        opts.half_unroll = int(half_unroll)
         nr = np.asarray(self.n_rows, dtype=np.int32)
         nc = np.asarray(self.n_cols, dtype=np.int32)
         kk = np.asarray(self.k, dtype=np.int32)
