@@ -185,7 +185,7 @@ def run_sharded(args) -> dict:
     dt = float(tmax.item())
     errs = drv.mean_errors()
     replicated = any(drv.replicated)
-    allgather = drv._allgather_blocks
+    allgather = drv.allgather_layout
     drv.close()
     roofline = None
     if rank == 0:      # the same streaming passes (rank 0's own view, same shape) timed per launch while the others wait

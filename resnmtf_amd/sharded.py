@@ -288,6 +288,11 @@ class ShardedSweep:
         return (arena.numel() == size * self.n_views and
                 all(b.numel() == size and b.data_ptr() == arena.data_ptr() + v * size * esz for v, b in enumerate(blocks)))
 
+    @property
+    def allgather_layout(self) -> bool:
+        """True when the F exchange blocks travel by one all-gather per sweep (one view per rank, equal blocks)."""
+        return self._allgather_blocks
+
     # ------------------------------------------------------------------
     def _allgather(self):
         """Every rank's F exchange block to every rank (end of a sweep / after the run prologue)."""

@@ -144,7 +144,7 @@ def main():
         opts = {"no_f_chain": True} if a.mode == "gpu_chain_off" else {}
         drv = sharded.ShardedSweep(prob, owner_of, a.rank, a.world, device_index=0, replicate_f=(a.mode != "gpu_norep"), **opts)
         assert any(drv.replicated) == (a.mode != "gpu_norep")
-        assert drv._allgather_blocks == one_per_rank
+        assert drv.allgather_layout == one_per_rank
     drv.run(a.sweeps // 2)
     drv.run(a.sweeps - a.sweeps // 2)          # two calls: state carries over
     mirrors_ok = True
