@@ -143,3 +143,29 @@ def test_sharded_hip_fused_f_chain(tmp_path, world, xi):
         assert rel_fro(got[f"output_s{v}"], ref["output_s"][v]) < 1e-4
         assert rel_fro(got[f"output_f{v}"], off[f"output_f{v}"]) < 1e-10
         assert np.array_equal(got[f"row_clusters{v}"], ref["row_clusters"][v])
+
+
+def test_allgather_layout_eligibility():
+    """Host logic only: the blocks travel by one all-gather iff every rank owns exactly one view (view v on rank v),
+    every view is replicated and the blocks tile one arena evenly."""
+    import torch
+    from resnmtf_amd import sharded
+
+    class FakeEngine:
+        def __init__(self, sizes):
+            self.arena = torch.zeros(sum(sizes), dtype=torch.float64)
+            self.off = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+
+        def factor_tensor(self, v, which):
+            return self.arena if which == "FBLOCK_ALL" else self.arena[self.off[v]:self.off[v + 1]]
+
+    prob = sharded.local_problem(2, (64, 48), 4, phi=1.0, owned=[])
+    mk = lambda sizes, owner_of, world, **kw: sharded.ShardedSweep(prob, owner_of, 0, world, engine=FakeEngine(sizes),
+                                                                  replicate_f=True, **kw)
+    assert mk([32, 32], [0, 1], 2).allgather_layout
+    assert not mk([32, 40], [0, 1], 2).allgather_layout            # unequal blocks
+    assert not mk([32, 32], [1, 0], 2).allgather_layout            # view v not on rank v
+    assert not mk([32, 32], [0, 1], 2, allgather_blocks=False).allgather_layout
+    uncoupled = sharded.local_problem(2, (64, 48), 4, phi=0.0, owned=[])
+    drv = sharded.ShardedSweep(uncoupled, [0, 1], 0, 2, engine=FakeEngine([32, 32]), replicate_f=True)
+    assert not any(drv.replicated) and not drv.allgather_layout    # nothing to exchange at all
