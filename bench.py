@@ -174,6 +174,7 @@ def run_sharded(args) -> dict:
                                   if "RESNMTF_SERIAL_EXCHANGE" in os.environ else {}))
     if os.environ.get("RESNMTF_FORCE_BCAST") == "1":      # rehearsal: issue the F broadcast even with one rank
         drv.plan[0]["F"] = True
+    drv.reserve(args.warmup + args.steps + 8)      # per-sweep error slots for both run() calls
     drv.run(args.warmup)
     dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -374,6 +374,13 @@ class ShardedSweep:
             else:
                 self._ev_g = ev
 
+    def reserve(self, total_sweeps: int):
+        """Room for the per-sweep errors of ``total_sweeps`` sweeps over all run() calls; call before the first run()
+        when more than max(1024, first n_sweeps) sweeps will follow."""
+        if self._prepared:
+            raise RuntimeError("reserve() must precede the first run()")
+        self._want_reserved = int(total_sweeps)
+
     def run(self, n_sweeps: int):
         """``n_sweeps`` more sweeps (fixed-iteration mode, R/main.r:83-108)."""
         if n_sweeps <= 0:
@@ -387,10 +394,10 @@ class ShardedSweep:
 
     def _run(self, n_sweeps: int):
         if not self._prepared:
-            self.engine.reserve_sweeps(max(1024, n_sweeps))
+            self._reserved = max(1024, n_sweeps, getattr(self, "_want_reserved", 0))
+            self.engine.reserve_sweeps(self._reserved)
             self.engine.prepare()
             self._prepared = True
-            self._reserved = max(1024, n_sweeps)
             self._gs_exchanged = any(p["G"] or p["S"] for p in self.plan)
             if any(self.replicated):      # the run prologue filled the owners' blocks: hand them round once
                 if self._tstream is not None and self._xstream is not self._tstream:
