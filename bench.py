@@ -175,10 +175,12 @@ def run_sharded(args) -> dict:
     if os.environ.get("RESNMTF_FORCE_BCAST") == "1":      # rehearsal: issue the F broadcast even with one rank
         drv.plan[0]["F"] = True
     drv.reserve(args.warmup + args.steps + 8)      # per-sweep error slots for both run() calls
-    drv.run(args.warmup)
+    # RESNMTF_SHARDED_GRAPH=K (opt-in, RCCL only): K sweeps incl. their collectives replayed from one captured graph
+    chunk = int(os.environ.get("RESNMTF_SHARDED_GRAPH", "0")) if backend == "nccl" else 0
+    drv.run(args.warmup, graph_chunk=chunk)
     dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    drv.run(args.steps)
+    drv.run(args.steps, graph_chunk=chunk)
     dist.barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")

@@ -381,16 +381,45 @@ class ShardedSweep:
             raise RuntimeError("reserve() must precede the first run()")
         self._want_reserved = int(total_sweeps)
 
-    def run(self, n_sweeps: int):
-        """``n_sweeps`` more sweeps (fixed-iteration mode, R/main.r:83-108)."""
+    def run(self, n_sweeps: int, graph_chunk: int = 0):
+        """``n_sweeps`` more sweeps (fixed-iteration mode, R/main.r:83-108).
+
+        ``graph_chunk`` > 0 (one-stream layouts on RCCL only, OFF by default): ``graph_chunk`` sweeps -- the library's
+        launches and the collectives between them -- are captured once in a ``torch.cuda.CUDAGraph`` and replayed.
+        Measured with one rank: 46.5 instead of 54.1 us per sweep; not yet validated on several GPUs, hence opt-in."""
         if n_sweeps <= 0:
             return
         if self._tstream is not None:
             import torch
             with torch.cuda.stream(self._xstream):      # one context switch per call, not one per broadcast
-                self._run(n_sweeps)
+                if graph_chunk > 0 and self._xstream is self._tstream and n_sweeps >= graph_chunk:
+                    n_sweeps = self._run_graphed(n_sweeps, int(graph_chunk))
+                if n_sweeps > 0:
+                    self._run(n_sweeps)
             return
         self._run(n_sweeps)
+
+    def _run_graphed(self, n_sweeps: int, chunk: int) -> int:
+        """Replays of a captured chunk; returns the sweeps left for the eager loop."""
+        import torch
+        self._run(0)                                    # run prologue and first exchange: outside the capture
+        if self.sweeps_done + n_sweeps > self._reserved:
+            raise RuntimeError("reserve more sweeps before the first run() (errors are kept per sweep)")
+        graphs = self.__dict__.setdefault("_graphs", {})
+        g = graphs.get(chunk)
+        if g is None:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            before = self.sweeps_done
+            with torch.cuda.graph(g, stream=self._tstream):
+                self._run(chunk)
+            self.sweeps_done = before                   # capturing enqueued nothing
+            graphs[chunk] = g
+        while n_sweeps >= chunk:
+            g.replay()
+            self.sweeps_done += chunk
+            n_sweeps -= chunk
+        return n_sweeps
 
     def _run(self, n_sweeps: int):
         if not self._prepared:

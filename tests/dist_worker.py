@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--rank", type=int, required=True)
     ap.add_argument("--world", type=int, required=True)
     ap.add_argument("--port", type=int, required=True)
-    ap.add_argument("--mode", choices=["cpu", "gpu", "gpu_norep", "gpu_allgather", "gpu_chain", "gpu_chain_off"], required=True)
+    ap.add_argument("--mode", choices=["cpu", "gpu", "gpu_norep", "gpu_allgather", "gpu_chain", "gpu_chain_off", "gpu_graph1"], required=True)
     ap.add_argument("--sweeps", type=int, default=12)
     ap.add_argument("--xi", type=float, default=0.4)
     ap.add_argument("--out", required=True)
@@ -133,6 +133,25 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
     from resnmtf_amd import sharded
+    if a.mode == "gpu_graph1":          # one rank on RCCL: the captured-chunk replay against the eager loop
+        import torch
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        prob = sharded.local_problem(1, (512, 192), 7, phi=1.0, owned=[0])
+        outs = []
+        for chunk in (0, 4):
+            drv = sharded.ShardedSweep(prob, [0], 0, 1, device_index=0, replicate_f="force")
+            assert drv.allgather_layout
+            drv.run(5, graph_chunk=chunk)
+            drv.run(a.sweeps - 5, graph_chunk=chunk)          # 4-sweep replays + eager remainder
+            torch.cuda.synchronize()
+            outs.append((drv.mean_errors(), drv.gather_results(0)))
+            drv.close()
+        same = np.array_equal(outs[0][0], outs[1][0]) and all(
+            np.array_equal(x, y) for key in outs[0][1] for x, y in zip(outs[0][1][key], outs[1][1][key]))
+        np.savez(a.out, same=np.array(same), all_error=outs[1][0])
+        dist.destroy_process_group()
+        return
     dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
     one_per_rank = a.mode in ("gpu_allgather", "gpu_chain", "gpu_chain_off")
     prob = build_problem_one_view_per_rank(a.world, identity=a.mode != "gpu_allgather", xi=a.xi) if one_per_rank else build_problem()

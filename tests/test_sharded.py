@@ -169,3 +169,12 @@ def test_allgather_layout_eligibility():
     uncoupled = sharded.local_problem(2, (64, 48), 4, phi=0.0, owned=[])
     drv = sharded.ShardedSweep(uncoupled, [0, 1], 0, 2, engine=FakeEngine([32, 32]), replicate_f=True)
     assert not any(drv.replicated) and not drv.allgather_layout    # nothing to exchange at all
+
+
+@pytest.mark.gpu
+def test_sharded_graph_chunk_replay_one_rank_rccl(tmp_path):
+    """Opt-in graph_chunk: sweeps of the sharded loop (library launches + the in-place RCCL all-gather) captured in one
+    graph and replayed must give bitwise the eager loop's results (one rank: RCCL refuses two ranks on one GPU)."""
+    got = launch("gpu_graph1", tmp_path, world=1, sweeps=19)
+    assert bool(got["same"])
+    assert len(got["all_error"]) == 19 and np.isfinite(got["all_error"]).all()
