@@ -1330,11 +1330,14 @@ static void build_chain(resnmtf_handle* h) {
   const int V = h->V;
   if (V < 2 || V > 8 || h->opt.no_f_chain) return;
   const ViewState& v0 = h->views[0];
-  int n_owned = 0;
+  int n_owned = 0, kpack = -1;
   for (int v = 0; v < V; ++v) {
     const ViewState& vs = h->views[v];
     if (!vs.owned && !vs.f_replica) return;
-    if (vs.owned && vs.half != v0.half && v0.owned) return;
+    if (vs.owned) {                                         // one operand-copy layout for all owned views
+      if (kpack < 0) kpack = vs.half ? 1 : 0;
+      else if (kpack != (vs.half ? 1 : 0)) return;
+    }
     if (vs.KP != 16 || vs.kk_mode != 0 || vs.n != v0.n || vs.k != v0.k || vs.rpbF != v0.rpbF || vs.nblkF != v0.nblkF) return;
     if (vs.argF.nsplit > 4 || vs.argF.cols_pad != v0.argF.cols_pad) return;     // raw split slabs the kernel keeps per view
     if (vs.owned) ++n_owned;
@@ -1347,7 +1350,7 @@ static void build_chain(resnmtf_handle* h) {
   a.len = v0.n; a.k = v0.k; a.n_views = V; a.rows_per_block = v0.rpbF;
   a.ctl = h->ctl;
   a.pstride = (size_t)v0.argF.cols_pad * 16;
-  a.kpack32 = v0.half ? 1 : 0;
+  a.kpack32 = kpack > 0 ? 1 : 0;
   for (int v = 0; v < 8; ++v) a.emit_slot[v] = -1;
   for (int v = 0; v < V; ++v) {
     const ViewState& vs = h->views[v];
