@@ -101,11 +101,13 @@ typedef struct resnmtf_options {
                              computes the phi-coupled F chain locally -- identical kernels on identical bytes,
                              so bitwise the same F everywhere -- instead of waiting for N serial F broadcasts */
   int no_f_chain;         /* 1: RESNMTF_PHASE_F_ALL always issues one launch per view (A/B testing) */
-  int x_half;             /* 1: k <= 16 -- the two passes stream a K-packed fp16 image of X (per-view power-of-two scale, 11-bit
+  int x_half;             /* (2: as 1 with UNIFORM 16-bit integers -- one power-of-two step per view -- widened exactly to f32 and
+                             multiplied on the f32 MFMA: F / G within 1e-6 ... 3e-5, inside the bar on every problem tried.)
+                             1: k <= 16 -- the two passes stream a K-packed fp16 image of X (per-view power-of-two scale, 11-bit
                              mantissa) instead of the f32 one: half the bytes; the factor operand stays f32-grade (two fp16
                              pieces, 22 bits), f32 accumulate.  F / G then sit within ~2e-5 of the fp64 reference instead of
                              ~1e-6 (bar 1e-4); DESIGN.md section 3 */
-  int half_unroll;        /* fp16 passes: wave-steps (16 rows each) per trip: 2, 3, 4 (default) or 6 */
+  int half_unroll;        /* 2-byte passes: wave-steps (16 rows each) per trip: 2, 3, 4 or 6 (0 = default: 4 for fp16, 2 for integers) */
 } resnmtf_options;
 
 typedef struct resnmtf_pass_timing {

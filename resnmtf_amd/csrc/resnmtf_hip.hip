@@ -47,7 +47,7 @@ struct ViewState {
   size_t ldx = 0, ldxt = 0;      // TILE strides of X32 / Xt32 (floats): tile t (64 columns) is a contiguous [rows_pad][64] block
   size_t x32_floats = 0, xt32_floats = 0;
   // fp16 passes (resnmtf_options.x_half, k <= 16): K-packed fp16 images of X / X^T, their tile strides (halves), scale
-  bool half = false;
+  bool half = false, u16 = false;   // u16: uniform 16-bit integers instead of fp16 (x_half = 2)
   _Float16 *X16 = nullptr, *Xt16 = nullptr;
   size_t ld16x = 0, ld16xt = 0, x16_halves = 0, xt16_halves = 0;
   float xscale = 1.f;
@@ -265,12 +265,17 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
   // three-piece bf16 split (f32-grade, default), 1 = two-piece (16-bit mantissa, fastest), 2 = plain f32
   const int split = v.NT < 2 ? 0 : (h->opt.bf16_split == 1 ? 2 : (h->opt.bf16_split == 2 ? 0 : 3));
   if (v.half) {       // fp16 image of X: the run-time scale (set at upload) is taken out in the slab store
-    a.out_scale = 1.f / (v.xscale * RESNMTF_B16_SCALE);
-    const int un = h->opt.half_unroll == 2 ? 2 : (h->opt.half_unroll == 6 ? 6 : (h->opt.half_unroll == 3 ? 3 : 4));
-#define LAUNCH_HALF(UV, XG)                                                                                             \
-    if (timed) hipExtLaunchKernelGGL((pass_half_kernel<UV, XG>), grid, block, smem, h->stream, ev0, ev1, 0, a, kf, ks);  \
-    else hipLaunchKernelGGL((pass_half_kernel<UV, XG>), grid, block, smem, h->stream, a, kf, ks)
-#define LAUNCH_HALF_U(UV) if (xg) { LAUNCH_HALF(UV, true); } else { LAUNCH_HALF(UV, false); }
+    a.out_scale = v.u16 ? 1.f / v.xscale : 1.f / (v.xscale * RESNMTF_B16_SCALE);
+    // wave-steps per trip: 4 for fp16; 2 for the 16-bit integers (their widening to f32 wants the registers: c2 26.5 k
+    // sweeps/s at 2, 23.5 k at 4)
+    const int un_def = v.u16 ? 2 : 4;
+    const int un = h->opt.half_unroll == 2 ? 2 : (h->opt.half_unroll == 6 ? 6 : (h->opt.half_unroll == 3 ? 3 : (h->opt.half_unroll == 4 ? 4 : un_def)));
+#define LAUNCH_HALF(UV, XG, U)                                                                                             \
+    if (timed) hipExtLaunchKernelGGL((pass_half_kernel<UV, XG, U>), grid, block, smem, h->stream, ev0, ev1, 0, a, kf, ks);  \
+    else hipLaunchKernelGGL((pass_half_kernel<UV, XG, U>), grid, block, smem, h->stream, a, kf, ks)
+#define LAUNCH_HALF_U(UV)                                                     \
+    if (v.u16) { if (xg) { LAUNCH_HALF(UV, true, true); } else { LAUNCH_HALF(UV, false, true); } } \
+    else { if (xg) { LAUNCH_HALF(UV, true, false); } else { LAUNCH_HALF(UV, false, false); } }
     switch (un) {
       case 2: LAUNCH_HALF_U(2); break;
       case 3: LAUNCH_HALF_U(3); break;
@@ -733,7 +738,8 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     if ((e = dev_alloc_zero(&vs.xnorm2, 1)) != hipSuccess) return bail(e, "hipMalloc xnorm2");
     if ((e = dev_alloc_zero(&vs.X32, vs.x32_floats)) != hipSuccess) return bail(e, "hipMalloc X32");
     if ((e = dev_alloc_zero(&vs.Xt32, vs.xt32_floats)) != hipSuccess) return bail(e, "hipMalloc Xt32");
-    vs.half = o.x_half == 1 && vs.NT == 1 && vs.kk_mode == 0 && vs.nw_xg == 8 && vs.nw_xtf == 8;
+    vs.half = (o.x_half == 1 || o.x_half == 2) && vs.NT == 1 && vs.kk_mode == 0 && vs.nw_xg == 8 && vs.nw_xtf == 8;
+    vs.u16 = vs.half && o.x_half == 2;
     if (vs.half) {      // one spare row group per tile keeps the tile starts off a common power-of-two stride
       vs.ld16x = ((size_t)vs.n_pad + 4) * 64; vs.ld16xt = ((size_t)vs.m_pad + 4) * 64;
       vs.x16_halves = (size_t)(vs.m_pad / 64) * vs.ld16x; vs.xt16_halves = (size_t)(vs.n_pad / 64) * vs.ld16xt;
@@ -808,11 +814,14 @@ int build_half_images(resnmtf_handle* h, ViewState& vs) {
   std::memcpy(&mx, &bits, sizeof(mx));
   int ex = 0;
   vs.xscale = 1.f;
-  if (mx > 0.f && std::isfinite(mx)) { (void)std::frexp(mx, &ex); vs.xscale = std::ldexp(1.f, 14 - ex); }   // max * scale in [2^13, 2^14)
+  if (mx > 0.f && std::isfinite(mx)) {
+    (void)std::frexp(mx, &ex);
+    vs.xscale = std::ldexp(1.f, (vs.u16 ? 16 : 14) - ex);      // max * scale in [2^13, 2^14) (fp16) / [2^15, 2^16) (u16)
+  }
   hipLaunchKernelGGL(pack_half_kernel, dim3((unsigned)(((size_t)(vs.n_pad / 4) * 64 * (vs.m_pad / 64) + 255) / 256)), dim3(256), 0,
-                     h->stream, vs.X32, vs.ldx, vs.n_pad, vs.m_pad / 64, vs.xscale, vs.X16, vs.ld16x);
+                     h->stream, vs.X32, vs.ldx, vs.n_pad, vs.m_pad / 64, vs.xscale, vs.X16, vs.ld16x, vs.u16 ? 1 : 0);
   hipLaunchKernelGGL(pack_half_kernel, dim3((unsigned)(((size_t)(vs.m_pad / 4) * 64 * (vs.n_pad / 64) + 255) / 256)), dim3(256), 0,
-                     h->stream, vs.Xt32, vs.ldxt, vs.m_pad, vs.n_pad / 64, vs.xscale, vs.Xt16, vs.ld16xt);
+                     h->stream, vs.Xt32, vs.ldxt, vs.m_pad, vs.n_pad / 64, vs.xscale, vs.Xt16, vs.ld16xt, vs.u16 ? 1 : 0);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return RESNMTF_OK;

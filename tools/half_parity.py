@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Parity of the fp16-image passes (resnmtf_options.x_half) against the fp64 oracle, next to the f32 passes.
+"""Parity of the 2-byte-image passes (resnmtf_options.x_half: 1 = fp16, 2 = uniform 16-bit) against the fp64 oracle, next to the f32 passes.
     python tools/half_parity.py          (diagnostic; uses the oracle, so it lives outside the product)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +15,7 @@ for shapes, k, kw, iters in cases:
     prob = synth.make_problem(shapes, k, **kw)
     ref = run_oracle(prob, n_iters=iters)
     line = f"{str(shapes):38s} k={k:2d} it={iters:3d}"
-    for label, opts in (("f32", {}), ("f16", {"x_half": 1})):
+    for label, opts in (("f32", {}), ("f16", {"x_half": 1}), ("u16", {"x_half": 2})):
         res = run_hip(prob, n_iters=iters, **opts)
         ef = max(rel_fro(res["output_f"][v], ref["output_f"][v]) for v in range(len(shapes)))
         eg = max(rel_fro(res["output_g"][v], ref["output_g"][v]) for v in range(len(shapes)))
