@@ -37,3 +37,30 @@ for shapes, k, kw, iters in cases:
         eg = max(rel_fro(res["output_g"][v], ref["output_g"][v]) for v in range(len(shapes)))
         line += f" | {label}: F {ef:.1e} G {eg:.1e}"
     print(line, flush=True)
+
+# ---- wider value distributions (single view 600 x 300, k = 8, 150 sweeps): what an upload-time guard has to catch
+print("\nvalue distributions (u16 image): rel. quantisation error of X, F / G distance")
+rng = np.random.default_rng(5)
+n, m, k = 600, 300, 8
+base = synth.planted_view(n, m, k, 77, normalise=False)
+variants = {
+    "planted blocks (the bench data)": base,
+    "blocks + 20 outliers x100": base + 100.0 * base.max() * (rng.random((n, m)) < 20.0 / (n * m)),
+    "blocks + 1 outlier x10000": base + 1e4 * base.max() * (np.arange(n * m).reshape(n, m) == 12345),
+    "lognormal(0, 2), no structure": rng.lognormal(0.0, 2.0, (n, m)),
+    "uniform(0, 1), no structure": rng.random((n, m)),
+    "90 % zeros, blocks": base * (rng.random((n, m)) < 0.1),
+    "columns scaled 1 .. 1e4 (undone by normalisation)": base * np.logspace(0, 4, m)[None, :],
+    "rows scaled 1 .. 1e4": base * np.logspace(0, 4, n)[:, None],
+}
+f0, s0, g0 = synth.random_init(n, m, k, 99)
+z = np.zeros((1, 1))
+for name, raw in variants.items():
+    x = raw / raw.sum(axis=0)[None, :]
+    xq = q_u16(x)
+    rel = np.linalg.norm(xq - x) / np.linalg.norm(x)
+    pa = Problem([x], [f0], [s0], [g0], z, z, z, k)
+    pb = Problem([xq], [f0], [s0], [g0], z, z, z, k)
+    ra, rb = run_oracle(pa, n_iters=150), run_oracle(pb, n_iters=150)
+    print(f"{name:52s} |dX|/|X| {rel:.1e}   F {rel_fro(rb['output_f'][0], ra['output_f'][0]):.1e}  G {rel_fro(rb['output_g'][0], ra['output_g'][0]):.1e}",
+          flush=True)
