@@ -125,11 +125,13 @@ def run_single(args) -> dict:
 
     roofline = pass_roofline(make_engine, args.steps, args.warmup)
 
-    # informational only (never `value`): the same workload with the opt-in 16-bit integer image of X
-    # (resnmtf_options.x_half = 2: half the pass bytes; F / G 1e-6 ... 3e-5 from the oracle instead of ~1e-7)
+    # informational only (never `value`): the same workload with the opt-in, guarded 16-bit integer image of X
+    # (resnmtf_options.x_half = 3: half the pass bytes when the image's relative quantisation error is <= 3e-5;
+    # F / G then 1e-6 ... 3e-5 from the oracle instead of ~1e-7)
     alt = None
     try:
-        eng3, _ = make_engine(x_half=2)
+        eng3, _ = make_engine(x_half=3)
+        kind, rel = eng3.view_image_info(0)
         if args.warmup > 0:
             eng3.run(args.warmup)
         torch.cuda.synchronize()
@@ -139,7 +141,8 @@ def run_single(args) -> dict:
         dt3 = time.perf_counter() - t1
         eng3.close()
         alt = {"view_updates_per_s": round(args.steps / dt3, 2), "final_error": float(errs3[-1]),
-               "note": "opt-in x_half=2 (uniform 16-bit image of X, f32 MFMA); not the default path, not `value`"}
+               "image": {0: "f32 (guard refused)", 1: "fp16", 2: "u16"}.get(kind, str(kind)), "x_rel_quantisation_error": rel,
+               "note": "opt-in x_half=3 (guarded uniform 16-bit image of X, f32 MFMA); not the default path, not `value`"}
     except Exception as exc:
         print(f"[bench] x_half=2 leg failed: {exc}", file=sys.stderr)
     cpu = cpu_baseline(prob) if not args.no_cpu_baseline else None

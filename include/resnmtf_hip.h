@@ -101,7 +101,9 @@ typedef struct resnmtf_options {
                              computes the phi-coupled F chain locally -- identical kernels on identical bytes,
                              so bitwise the same F everywhere -- instead of waiting for N serial F broadcasts */
   int no_f_chain;         /* 1: RESNMTF_PHASE_F_ALL always issues one launch per view (A/B testing) */
-  int x_half;             /* (2: as 1 with UNIFORM 16-bit integers -- one power-of-two step per view -- widened exactly to f32 and
+  int x_half;             /* (3: as 2, but per view only when the image's relative quantisation error || X~ - X || / || X ||,
+                             measured at upload, is at most 3e-5 -- F / G move by 0.2 ... 2 x that error; else the f32 images.)
+                             (2: as 1 with UNIFORM 16-bit integers -- one power-of-two step per view -- widened exactly to f32 and
                              multiplied on the f32 MFMA: F / G within 1e-6 ... 3e-5, inside the bar on every problem tried.)
                              1: k <= 16 -- the two passes stream a K-packed fp16 image of X (per-view power-of-two scale, 11-bit
                              mantissa) instead of the f32 one: half the bytes; the factor operand stays f32-grade (two fp16
@@ -252,6 +254,11 @@ int resnmtf_finalise(resnmtf_handle* h, int v, double* F, double* S, double* G,
                      double* row_clusters, double* col_clusters);
 
 /* ---- phase-level entry points (views sharded one-per-GPU; host does the exchange) ---- */
+
+/* Which image of X the streaming passes of view v use after its upload: *uses_2byte = 0 (f32 images), 1 (fp16) or
+ * 2 (uniform 16-bit integers); *rel_error = || X~ - X ||_F / || X ||_F of the 2-byte image (0 when none was built).
+ * With x_half = 3 this is the guard's decision (resnmtf_options). */
+int resnmtf_view_image_info(resnmtf_handle* h, int v, int* uses_2byte, double* rel_error);
 
 /* Size the per-sweep error buffer for `sweeps` sweeps (phase mode; resnmtf_run sizes it itself).
  * Must precede resnmtf_prepare. */

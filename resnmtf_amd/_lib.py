@@ -78,6 +78,7 @@ SIGNATURES = {
     "resnmtf_view_errors": (C.c_int, [_h, C.c_int, C.c_int, C.c_int, _dp]),
     "resnmtf_synchronize": (C.c_int, [_h]),
     "resnmtf_pass_timings": (C.c_int, [_h, C.POINTER(PassTiming), C.c_int]),
+    "resnmtf_view_image_info": (C.c_int, [_h, C.c_int, _ip, _dp]),
 }
 
 _lib = None

@@ -47,7 +47,9 @@ struct ViewState {
   size_t ldx = 0, ldxt = 0;      // TILE strides of X32 / Xt32 (floats): tile t (64 columns) is a contiguous [rows_pad][64] block
   size_t x32_floats = 0, xt32_floats = 0;
   // fp16 passes (resnmtf_options.x_half, k <= 16): K-packed fp16 images of X / X^T, their tile strides (halves), scale
-  bool half = false, u16 = false;   // u16: uniform 16-bit integers instead of fp16 (x_half = 2)
+  bool half = false, u16 = false;   // u16: uniform 16-bit integers instead of fp16 (x_half = 2, 3)
+  bool half_capable = false;        // the 2-byte images are allocated; `half` says whether the passes use them (x_half = 3: guard)
+  double x_relerr = 0.0;            // || X~ - X ||_F / || X ||_F of the 2-byte image (set at upload)
   _Float16 *X16 = nullptr, *Xt16 = nullptr;
   size_t ld16x = 0, ld16xt = 0, x16_halves = 0, xt16_halves = 0;
   float xscale = 1.f;
@@ -738,8 +740,9 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     if ((e = dev_alloc_zero(&vs.xnorm2, 1)) != hipSuccess) return bail(e, "hipMalloc xnorm2");
     if ((e = dev_alloc_zero(&vs.X32, vs.x32_floats)) != hipSuccess) return bail(e, "hipMalloc X32");
     if ((e = dev_alloc_zero(&vs.Xt32, vs.xt32_floats)) != hipSuccess) return bail(e, "hipMalloc Xt32");
-    vs.half = (o.x_half == 1 || o.x_half == 2) && vs.NT == 1 && vs.kk_mode == 0 && vs.nw_xg == 8 && vs.nw_xtf == 8;
-    vs.u16 = vs.half && o.x_half == 2;
+    vs.half = (o.x_half >= 1 && o.x_half <= 3) && vs.NT == 1 && vs.kk_mode == 0 && vs.nw_xg == 8 && vs.nw_xtf == 8;
+    vs.u16 = vs.half && o.x_half >= 2;
+    vs.half_capable = vs.half;
     if (vs.half) {      // one spare row group per tile keeps the tile starts off a common power-of-two stride
       vs.ld16x = ((size_t)vs.n_pad + 4) * 64; vs.ld16xt = ((size_t)vs.m_pad + 4) * 64;
       vs.x16_halves = (size_t)(vs.m_pad / 64) * vs.ld16x; vs.xt16_halves = (size_t)(vs.n_pad / 64) * vs.ld16xt;
@@ -798,32 +801,59 @@ namespace {
 // Source of the staging image: the host matrix x, or (x == NULL) a pseudo-random permutation of the
 // entries of another view's device copy (shuffle_src, see resnmtf_shuffle_view).
 // fp16 images of an uploaded view: per-view power-of-two scale that puts the largest entry near 2^14
+// relative quantisation error of X below which the guarded mode (x_half = 3) lets the passes use the 16-bit image:
+// F / G move by 0.2 ... 2 x that error (tools/quant_study.py), the bar is 1e-4
+constexpr double kHalfGuard = 3.0e-5;
 int build_half_images(resnmtf_handle* h, ViewState& vs) {
-  unsigned int* dmax = nullptr;
-  HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&dmax), sizeof(unsigned int)));
-  hipError_t e = hipMemsetAsync(dmax, 0, sizeof(unsigned int), h->stream);
+  double* scratch = nullptr;          // [0] = max entry bits (as unsigned), [1] = sum (x~ - x)^2, [2] = copy of ||X||^2
+  HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&scratch), 3 * sizeof(double)));
+  hipError_t e = hipMemsetAsync(scratch, 0, 3 * sizeof(double), h->stream);
   unsigned int bits = 0;
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(max_entry_kernel, dim3(1024), dim3(256), 0, h->stream, vs.X32, vs.x32_floats, dmax);
-    e = hipMemcpyAsync(&bits, dmax, sizeof(bits), hipMemcpyDeviceToHost, h->stream);
+    hipLaunchKernelGGL(max_entry_kernel, dim3(1024), dim3(256), 0, h->stream, vs.X32, vs.x32_floats,
+                       reinterpret_cast<unsigned int*>(scratch));
+    e = hipMemcpyAsync(&bits, scratch, sizeof(bits), hipMemcpyDeviceToHost, h->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  (void)hipFree(dmax);
-  if (e != hipSuccess) return h->fail_hip("half images (max)", e);
+  if (e != hipSuccess) { (void)hipFree(scratch); return h->fail_hip("2-byte images (max)", e); }
   float mx;
   std::memcpy(&mx, &bits, sizeof(mx));
   int ex = 0;
   vs.xscale = 1.f;
   if (mx > 0.f && std::isfinite(mx)) {
     (void)std::frexp(mx, &ex);
-    vs.xscale = std::ldexp(1.f, (vs.u16 ? 16 : 14) - ex);      // max * scale in [2^13, 2^14) (fp16) / [2^15, 2^16) (u16)
+    // fp16: power of two, max * scale in [2^13, 2^14) (exact scaling); integers: the full range, max -> 65535 (the
+    // widening is exact whatever the step, the step is taken out once per output in f32)
+    vs.xscale = vs.u16 ? 65535.f / mx : std::ldexp(1.f, 14 - ex);
   }
   hipLaunchKernelGGL(pack_half_kernel, dim3((unsigned)(((size_t)(vs.n_pad / 4) * 64 * (vs.m_pad / 64) + 255) / 256)), dim3(256), 0,
-                     h->stream, vs.X32, vs.ldx, vs.n_pad, vs.m_pad / 64, vs.xscale, vs.X16, vs.ld16x, vs.u16 ? 1 : 0);
+                     h->stream, vs.X32, vs.ldx, vs.n_pad, vs.m_pad / 64, vs.xscale, vs.X16, vs.ld16x, vs.u16 ? 1 : 0, scratch + 1);
   hipLaunchKernelGGL(pack_half_kernel, dim3((unsigned)(((size_t)(vs.m_pad / 4) * 64 * (vs.n_pad / 64) + 255) / 256)), dim3(256), 0,
-                     h->stream, vs.Xt32, vs.ldxt, vs.m_pad, vs.n_pad / 64, vs.xscale, vs.Xt16, vs.ld16xt, vs.u16 ? 1 : 0);
-  HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+                     h->stream, vs.Xt32, vs.ldxt, vs.m_pad, vs.n_pad / 64, vs.xscale, vs.Xt16, vs.ld16xt, vs.u16 ? 1 : 0,
+                     (double*)nullptr);
+  double host[2] = {0.0, 0.0};
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(&host[0], scratch + 1, sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&host[1], vs.xnorm2, sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(scratch);
+  if (e != hipSuccess) return h->fail_hip("2-byte images (pack)", e);
+  vs.x_relerr = host[1] > 0.0 ? std::sqrt(host[0] / host[1]) : 0.0;
+  const bool use = h->opt.x_half == 3 ? vs.x_relerr <= kHalfGuard : true;
+  if (use != vs.half) {               // the factor operand copies follow the image's layout: rewrite them
+    vs.half = use;
+    if (vs.has_factors) {
+      HIP_TRY(h, hipMemsetAsync(vs.F32, 0, (size_t)vs.n_pad * 64 * sizeof(float), h->stream));
+      HIP_TRY(h, hipMemsetAsync(vs.G32, 0, (size_t)vs.m_pad * 64 * sizeof(float), h->stream));
+      hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(vs.n * vs.k, 256)), dim3(256), 0, h->stream, vs.F, vs.n,
+                         vs.k, vs.F32, vs.kk_mode == 0 ? vs.KP : 64, vs.NT, vs.half ? 1 : 0);
+      hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(vs.m * vs.k, 256)), dim3(256), 0, h->stream, vs.G, vs.m,
+                         vs.k, vs.G32, vs.kk_mode == 0 ? vs.KP : 64, vs.NT, vs.half ? 1 : 0);
+      HIP_TRY(h, hipGetLastError());
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+  }
+  h->prepared = false;
   return RESNMTF_OK;
 }
 struct ShuffleSrc { const float* X32; size_t ldx; unsigned long long seed; const int* rows; const int* cols; };   // rows != NULL: sub-sample
@@ -876,7 +906,7 @@ int upload_view(resnmtf_handle* h, int v, const double* x, bool raw, int* was_ne
   if (e != hipSuccess) return h->fail_hip("set_view", e);
   if (was_negative) *was_negative = neg_host;
   vs.has_x = true;
-  if (vs.half) return build_half_images(h, vs);
+  if (vs.half_capable) return build_half_images(h, vs);
   return RESNMTF_OK;
 }
 }  // namespace
@@ -913,7 +943,7 @@ int resnmtf_copy_view(resnmtf_handle* dst, int v, resnmtf_handle* src, int v_src
   HIP_TRY(dst, hipMemcpyAsync(a.xnorm2, b.xnorm2, sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
   HIP_TRY(dst, hipStreamSynchronize(dst->stream));
   a.has_x = true;
-  if (a.half) return build_half_images(dst, a);
+  if (a.half_capable) return build_half_images(dst, a);
   return RESNMTF_OK;
 }
 
@@ -1706,6 +1736,14 @@ int resnmtf_debug_set_stamp_buffer(unsigned long long* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : RESNMTF_ERR_HIP;
 }
 #endif
+
+int resnmtf_view_image_info(resnmtf_handle* h, int v, int* uses_2byte, double* rel_error) {
+  if (int rc = check_view(h, v)) return rc;
+  const ViewState& vs = h->views[v];
+  if (uses_2byte) *uses_2byte = vs.half ? (vs.u16 ? 2 : 1) : 0;
+  if (rel_error) *rel_error = vs.half_capable ? vs.x_relerr : 0.0;
+  return RESNMTF_OK;
+}
 
 int resnmtf_pass_timings(resnmtf_handle* h, resnmtf_pass_timing* out, int reset) {
   if (!h || !out) return RESNMTF_ERR_INVALID;

@@ -230,6 +230,14 @@ class Engine:
         self._check(self._lib.resnmtf_finalise(self._h, v, _dp(f), _dp(s), _dp(g), _dp(rc), _dp(cc)))
         return f, s, g, rc, cc
 
+    def view_image_info(self, v: int):
+        """(kind, rel_error): kind 0 = f32 images, 1 = fp16, 2 = uniform 16-bit integers; the relative quantisation
+        error of the 2-byte image of view ``v`` measured at upload (``x_half``)."""
+        kind = C.c_int(0)
+        rel = C.c_double(0.0)
+        self._check(self._lib.resnmtf_view_image_info(self._h, v, C.byref(kind), C.byref(rel)))
+        return int(kind.value), float(rel.value)
+
     def pass_timings(self, reset: bool = False) -> dict:
         t = _lib.PassTiming()
         self._check(self._lib.resnmtf_pass_timings(self._h, C.byref(t), 1 if reset else 0))

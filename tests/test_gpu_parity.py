@@ -466,3 +466,35 @@ def test_uniform_16bit_image_passes_inside_the_bar(shapes, k, kw, iters):
         assert np.array_equal(res["row_clusters"][v], ref["row_clusters"][v])
         assert np.array_equal(res["col_clusters"][v], ref["col_clusters"][v])
     np.testing.assert_allclose(res["All_Error"], ref["All_Error"], atol=5e-4)
+
+
+def test_guarded_16bit_image_falls_back_on_outliers():
+    """x_half = 3: the 16-bit integer image is used per view only when its relative quantisation error, measured at
+    upload, is at most 3e-5.  Planted blocks pass the guard; the same data with a few x100 outliers does not and runs on
+    the f32 images (f32-grade parity) -- factors uploaded BEFORE the data (operand copies rewritten) and after."""
+    from resnmtf_amd.engine import Engine
+    from resnmtf_amd.synth import Problem
+    n, m, k = 600, 300, 8
+    clean = synth.make_problem([(n, m)], k)
+    rng = np.random.default_rng(5)
+    raw = synth.planted_view(n, m, k, 77, normalise=False)
+    raw = raw + 100.0 * raw.max() * (rng.random((n, m)) < 20.0 / (n * m))
+    dirty = Problem([raw / raw.sum(axis=0)[None, :]], clean.init_f, clean.init_s, clean.init_g, clean.phi, clean.xi, clean.psi, k)
+    for prob, want_kind in ((clean, 2), (dirty, 0)):
+        ref = run_oracle(prob, n_iters=60)
+        for factors_first in (False, True):
+            with Engine([n], [m], [k], x_half=3) as e:
+                if factors_first:
+                    e.set_factors(0, prob.init_f[0], prob.init_s[0], prob.init_g[0])
+                e.set_view(0, prob.data[0])
+                if not factors_first:
+                    e.set_factors(0, prob.init_f[0], prob.init_s[0], prob.init_g[0])
+                e.set_restrictions(None, None, None)
+                kind, rel = e.view_image_info(0)
+                assert kind == want_kind, (kind, rel)
+                assert (rel <= 3e-5) == (want_kind == 2)
+                errs = e.run(60)
+                f, s, g, _, _ = e.finalise(0)
+            tol = 5e-5 if want_kind == 2 else TOL_FG
+            assert rel_fro(f, ref["output_f"][0]) < tol and rel_fro(g, ref["output_g"][0]) < tol
+            np.testing.assert_allclose(errs, ref["All_Error"], atol=5e-4 if want_kind == 2 else TOL_ERR)
