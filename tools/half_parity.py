@@ -25,3 +25,20 @@ for shapes, k, kw, iters in cases:
                    for v in range(len(shapes)))
         line += f" | {label}: F {ef:.1e} G {eg:.1e} S {es:.1e} err {ee:.1e} cl {mism}"
     print(line, flush=True)
+
+# ---- guarded mode over more seeds / shapes (support for making it the default): worst distances
+print("\nx_half = 3 (guarded 16-bit image) over seeds:")
+from resnmtf_amd.engine import Engine
+worst = 0.0
+for si, (shapes, k, kw, iters) in enumerate([([(500, 260)], 7, {}, 120), ([(1500, 400)], 16, {}, 150), ([(800, 800)], 10, {}, 100),
+                                              ([(700, 180), (700, 220)], 9, {"phi": 5.0}, 80), ([(256, 1024)], 4, {}, 150),
+                                              ([(640, 320)] * 3, 12, {"phi": 1.0, "xi": 0.5}, 80)]):
+    for seed in (11, 23, 37):
+        prob = synth.make_problem(shapes, k, seed_base=seed, **kw)
+        ref = run_oracle(prob, n_iters=iters)
+        res = run_hip(prob, n_iters=iters, x_half=3)
+        ef = max(rel_fro(res["output_f"][v], ref["output_f"][v]) for v in range(len(shapes)))
+        eg = max(rel_fro(res["output_g"][v], ref["output_g"][v]) for v in range(len(shapes)))
+        worst = max(worst, ef, eg)
+        print(f"  {str(shapes):34s} k={k:2d} seed {seed}: F {ef:.1e} G {eg:.1e}", flush=True)
+print(f"worst F / G distance: {worst:.2e}")
