@@ -95,9 +95,15 @@ struct resnmtf_handle {
   bool prepared = false;
   bool all_owned = true;
   // graphs
-  hipGraphExec_t graph_multi = nullptr, graph_one = nullptr;
-  int graph_multi_sweeps = 0;
+  // ladder of captured sweep graphs: check_every sweeps plus every smaller power of two, so that any run length
+  // is a handful of graph launches (R/main.r:83-108 is the loop being replayed)
+  std::vector<std::pair<int, hipGraphExec_t>> ladder;      // (sweeps, executable), descending
   double graph_tol = -2.0;
+  bool resume_ok = false;             // the device state is exactly what the run prologue would produce: skip it
+  SweepCtl* ctl_host = nullptr;       // pinned, device-mapped mirrors written by the k x k job of a sweep's last view /
+  double* err_host = nullptr;         //   every view (fixed-iteration runs end with one stream synchronisation, no copy)
+  SweepCtl* ctl_host_dev = nullptr;
+  double* err_host_dev = nullptr;
   int n_cu = 256;                     // compute units of the device (multiProcessorCount)
   ChainArgs<8> chain{};               // RESNMTF_PHASE_F_ALL: the F updates of every view in one launch (when eligible)
   int chain_views = 0;                // 0 = not eligible: one launch per view
@@ -451,10 +457,9 @@ void enqueue_sweep(resnmtf_handle* h, double tol) {
 }
 
 void destroy_graphs(resnmtf_handle* h) {
-  if (h->graph_multi) (void)hipGraphExecDestroy(h->graph_multi);
-  if (h->graph_one) (void)hipGraphExecDestroy(h->graph_one);
-  h->graph_multi = h->graph_one = nullptr;
-  h->graph_multi_sweeps = 0;
+  for (auto& rung : h->ladder)
+    if (rung.second) (void)hipGraphExecDestroy(rung.second);
+  h->ladder.clear();
   h->graph_tol = -2.0;
 }
 
@@ -466,6 +471,23 @@ int capture_graph(resnmtf_handle* h, int sweeps, double tol, hipGraphExec_t* out
   hipError_t e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
   (void)hipGraphDestroy(g);
   if (e != hipSuccess) return h->fail_hip("hipGraphInstantiate", e);
+  (void)hipGraphUpload(*out, h->stream);      // first replay does not pay the upload
+  return RESNMTF_OK;
+}
+// the whole ladder at once (a few hundred kernel nodes): a later run of any length never captures inside a timed region
+int capture_ladder(resnmtf_handle* h, int batch, double tol) {
+  destroy_graphs(h);
+  std::vector<int> rungs{batch};
+  int p2 = 1;
+  while (p2 * 2 < batch) p2 *= 2;
+  for (; p2 >= 1; p2 /= 2)
+    if (p2 < batch) rungs.push_back(p2);
+  for (int sweeps : rungs) {
+    hipGraphExec_t ex = nullptr;
+    if (int rc = capture_graph(h, sweeps, tol, &ex)) { destroy_graphs(h); return rc; }
+    h->ladder.emplace_back(sweeps, ex);
+  }
+  h->graph_tol = tol;
   return RESNMTF_OK;
 }
 
@@ -545,6 +567,23 @@ int sync_both(resnmtf_handle* h) {
   return RESNMTF_OK;
 }
 
+// pinned, device-mapped host mirror of the per-sweep errors ([cap][V]) and of the loop control
+hipError_t alloc_host_mirrors(resnmtf_handle* h, int cap) {
+  if (h->err_host) (void)hipHostFree(h->err_host);
+  h->err_host = nullptr; h->err_host_dev = nullptr;
+  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&h->err_host), (size_t)cap * h->V * sizeof(double),
+                               hipHostMallocMapped | hipHostMallocCoherent);
+  if (e != hipSuccess) return e;
+  std::memset(h->err_host, 0, (size_t)cap * h->V * sizeof(double));
+  if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->err_host_dev), h->err_host, 0)) != hipSuccess) return e;
+  if (!h->ctl_host) {
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->ctl_host), sizeof(SweepCtl), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return e;
+    std::memset(h->ctl_host, 0, sizeof(SweepCtl));
+    if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->ctl_host_dev), h->ctl_host, 0)) != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 int ensure_err_capacity(resnmtf_handle* h, int sweeps) {
   if (sweeps <= h->err_cap) return RESNMTF_OK;
   if (int rc = sync_both(h)) return rc;
@@ -553,6 +592,7 @@ int ensure_err_capacity(resnmtf_handle* h, int sweeps) {
   const int cap = std::max(sweeps, 1024);
   hipError_t e = dev_alloc_zero(&h->err, (size_t)cap * h->V);
   if (e == hipSuccess) e = hipDeviceSynchronize();      // (NULL-stream memset vs the handle's non-blocking stream)
+  if (e == hipSuccess) e = alloc_host_mirrors(h, cap);
   if (e != hipSuccess) { h->err_cap = 0; return h->fail_hip("hipMalloc err", e); }
   h->err_cap = cap;
   h->prepared = false;   // kernel argument blocks hold the pointer
@@ -658,6 +698,7 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
   if ((e = dev_alloc_zero(&h->ctl, 1)) != hipSuccess) return bail(e, "hipMalloc ctl");
   h->err_cap = 1024;
   if ((e = dev_alloc_zero(&h->err, (size_t)h->err_cap * n_views)) != hipSuccess) return bail(e, "hipMalloc err");
+  if ((e = alloc_host_mirrors(h, h->err_cap)) != hipSuccess) return bail(e, "hipHostMalloc error mirror");
   // replicate_f: one arena holds the F exchange block of every view, in view order (equal-shaped views
   // give equal strides, so that one in-place all-gather moves every rank's block -- sharded.py)
   auto fblk_usum_bytes = [](const ViewState& vs) { return ((size_t)vs.n_pad * vs.KP * sizeof(float) + 255) / 256 * 256; };
@@ -788,6 +829,8 @@ int resnmtf_destroy(resnmtf_handle* h) {
   if (h->fblk_arena) (void)hipFree(h->fblk_arena);
   if (h->ctl) (void)hipFree(h->ctl);
   if (h->err) (void)hipFree(h->err);
+  if (h->err_host) (void)hipHostFree(h->err_host);
+  if (h->ctl_host) (void)hipHostFree(h->ctl_host);
   for (auto& evt : h->ev)
     if (evt) (void)hipEventDestroy(evt);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -854,6 +897,7 @@ int build_half_images(resnmtf_handle* h, ViewState& vs) {
     }
   }
   h->prepared = false;
+  h->resume_ok = false;
   return RESNMTF_OK;
 }
 struct ShuffleSrc { const float* X32; size_t ldx; unsigned long long seed; const int* rows; const int* cols; };   // rows != NULL: sub-sample
@@ -862,6 +906,7 @@ int upload_view(resnmtf_handle* h, int v, const double* x, bool raw, int* was_ne
   if (!x && !shuffle_src) return h->fail(RESNMTF_ERR_INVALID, "x is NULL");
   ViewState& vs = h->views[v];
   if (!vs.owned) return h->fail(RESNMTF_ERR_STATE, "set_view on a view this handle does not own");
+  h->resume_ok = false;
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
   if (int rc = sync_both(h)) return rc;
   const size_t count = (size_t)vs.n * vs.m;
@@ -933,6 +978,7 @@ int resnmtf_copy_view(resnmtf_handle* dst, int v, resnmtf_handle* src, int v_src
   if (int rc = check_view_pair(dst, v, src, v_src)) return rc;
   ViewState& a = dst->views[v];
   const ViewState& b = src->views[v_src];
+  dst->resume_ok = false;
   HIP_TRY(dst, hipSetDevice(dst->opt.device_id));
   HIP_TRY(dst, hipStreamSynchronize(src->stream));
   if (int rc = sync_both(dst)) return rc;
@@ -998,6 +1044,7 @@ int resnmtf_set_factors(resnmtf_handle* h, int v, const double* F, const double*
   if (int rc = check_view(h, v)) return rc;
   if (!F || !S || !G) return h->fail(RESNMTF_ERR_INVALID, "F, S and G are required");
   ViewState& vs = h->views[v];
+  h->resume_ok = false;
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
   if (int rc = sync_both(h)) return rc;
   std::vector<double> f, s, g;
@@ -1231,6 +1278,7 @@ int resnmtf_init_svd(resnmtf_handle* h, int v, unsigned long long seed, double s
   if (!vs.owned || !vs.has_x) return h->fail(RESNMTF_ERR_STATE, "init_svd needs an owned view with data (set_view first)");
   if (n_power < 1) n_power = 3;
   if (!(sigma >= 0.0)) return h->fail(RESNMTF_ERR_INVALID, "sigma must be >= 0");
+  h->resume_ok = false;
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
   if (int rc = sync_both(h)) return rc;
   const int n = vs.n, m = vs.m, k = vs.k;
@@ -1321,6 +1369,7 @@ int resnmtf_set_restrictions(resnmtf_handle* h, const double* phi, const double*
     }
   }
   h->prepared = false;
+  h->resume_ok = false;
   return RESNMTF_OK;
 }
 
@@ -1334,6 +1383,7 @@ static int set_shared(resnmtf_handle* h, int v, int w, int count, const int* idx
   const int len_v = rows ? vs.n : vs.m, len_w = rows ? ws.n : ws.m;
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
   h->prepared = false;
+  h->resume_ok = false;
   if (count < 0) {           // NA
     mp.set = true; mp.count = -1;
     if (mp.dev) { (void)hipFree(mp.dev); mp.dev = nullptr; }
@@ -1499,6 +1549,7 @@ static int build_args(resnmtf_handle* h) {
     ks.S = vs.S; ks.lambda = vs.lambda; ks.mu = vs.mu; ks.Ma_F = vs.Ma_F; ks.Md_F = vs.Md_F;
     ks.xnorm2 = vs.xnorm2;
     ks.err = h->err; ks.err_stride = V; ks.err_col = v; ks.err_cap = h->err_cap;
+    ks.err_host = h->err_host_dev; ks.ctl_host = h->ctl_host_dev;
     ks.ctl = h->ctl; ks.last_view = (v == h->last_owned) ? 1 : 0; ks.n_views = V; ks.tol = -1.0;
     {
       double sigma = 0.0;
@@ -1527,22 +1578,31 @@ int resnmtf_reserve_sweeps(resnmtf_handle* h, int sweeps) {
   return ensure_err_capacity(h, sweeps);
 }
 
-int resnmtf_prepare(resnmtf_handle* h) {
-  if (!h) return RESNMTF_ERR_INVALID;
-  HIP_TRY(h, hipSetDevice(h->opt.device_id));
+// allow_resume: resnmtf_run directly after a completed resnmtf_run with nothing set in between -- the device state
+// (X.G slabs, F coefficients, Gram partials) is bit for bit what the run prologue would recompute, so only the loop
+// control is reset, in stream order, without a host synchronisation
+static int prepare_impl(resnmtf_handle* h, bool allow_resume) {
   if (!h->prepared) {
     destroy_graphs(h);
     if (int rc = build_args(h)) return rc;
     h->prepared = true;
   }
-  // run prologue: reset the loop control, F coefficients and the first X.G pass of every owned view
-  if (int rc = sync_both(h)) return rc;
-  SweepCtl zero{};
-  HIP_TRY(h, hipMemcpy(h->ctl, &zero, sizeof(zero), hipMemcpyHostToDevice));
+  std::memset(h->ctl_host, 0, sizeof(SweepCtl));
+  HIP_TRY(h, hipMemsetAsync(h->ctl, 0, sizeof(SweepCtl), h->stream));      // all-zero bytes = SweepCtl{}
+  if (allow_resume && h->resume_ok) return RESNMTF_OK;
+  // run prologue: F coefficients and the first X.G pass of every owned view
+  h->resume_ok = false;
   for (const auto& v : h->views)
     if (v.owned) enqueue_prologue(h, v);
   HIP_TRY(h, hipGetLastError());
   return RESNMTF_OK;
+}
+
+int resnmtf_prepare(resnmtf_handle* h) {
+  if (!h) return RESNMTF_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->opt.device_id));
+  if (int rc = sync_both(h)) return rc;
+  return prepare_impl(h, false);
 }
 
 int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep) {
@@ -1553,6 +1613,7 @@ int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep) {
     return h->fail(RESNMTF_ERR_STATE, "phase on a view this handle does not own");
   if (sweep < 0) return h->fail(RESNMTF_ERR_INVALID, "negative sweep index");
   if (sweep >= h->err_cap) return h->fail(RESNMTF_ERR_STATE, "sweep beyond the reserved error buffer (resnmtf_reserve_sweeps)");
+  h->resume_ok = false;
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
   switch (phase) {
     case RESNMTF_PHASE_F: enqueue_phase_f(h, vs, false); break;
@@ -1588,17 +1649,13 @@ int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, doubl
     if (total < 1) return h->fail(RESNMTF_ERR_INVALID, "convergence mode needs max_iters > 0 or an all_err buffer");
   }
   if (int rc = ensure_err_capacity(h, total)) return rc;
-  if (int rc = resnmtf_prepare(h)) return rc;
+  // (the host mirror of the loop control is rewritten below: the previous run has been waited for)
+  if (int rc = prepare_impl(h, true)) return rc;
+  h->resume_ok = false;
   const bool eager = !h->opt.use_graph || h->opt.time_kernels;
   const int batch = std::max(1, h->opt.check_every);
-  if (!eager && (h->graph_tol != tol_arg || !h->graph_one)) {
-    destroy_graphs(h);
-    if (int rc = capture_graph(h, 1, tol_arg, &h->graph_one)) return rc;
-    if (int rc = capture_graph(h, batch, tol_arg, &h->graph_multi)) return rc;
-    h->graph_multi_sweeps = batch;
-    h->graph_tol = tol_arg;
-  }
-  SweepCtl host_ctl{};
+  if (!eager && (h->graph_tol != tol_arg || h->ladder.empty() || h->ladder.front().first != batch))
+    if (int rc = capture_ladder(h, batch, tol_arg)) return rc;
   int enq = 0;
   while (enq < total) {
     const int todo = std::min(batch, total - enq);
@@ -1608,36 +1665,36 @@ int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, doubl
         if (h->opt.time_kernels && h->ev_used + 8 * (size_t)h->V > h->ev.size())
           if (int rc = flush_timing(h)) return rc;
       }
-    } else if (todo == h->graph_multi_sweeps) {
-      HIP_TRY(h, hipGraphLaunch(h->graph_multi, h->stream));
     } else {
-      for (int s = 0; s < todo; ++s) HIP_TRY(h, hipGraphLaunch(h->graph_one, h->stream));
+      int left = todo;                       // a full batch is one launch; a remainder a few (binary ladder)
+      for (const auto& rung : h->ladder)
+        while (left >= rung.first) {
+          HIP_TRY(h, hipGraphLaunch(rung.second, h->stream));
+          left -= rung.first;
+        }
     }
     enq += todo;
-    if (tol_arg >= 0.0) {     // convergence mode (R/main.r:50-81): look at the device flag between batches
+    if (tol_arg >= 0.0) {     // convergence mode (R/main.r:50-81): look at the (mirrored) device flag between batches
       HIP_TRY(h, hipGetLastError());
       if (int rc = sync_both(h)) return rc;
-      HIP_TRY(h, hipMemcpy(&host_ctl, h->ctl, sizeof(SweepCtl), hipMemcpyDeviceToHost));
-      if (host_ctl.done) break;
+      if (h->ctl_host->done) break;
     }
   }
   HIP_TRY(h, hipGetLastError());
   if (int rc = sync_both(h)) return rc;
-  HIP_TRY(h, hipMemcpy(&host_ctl, h->ctl, sizeof(SweepCtl), hipMemcpyDeviceToHost));
-  const int done_total = host_ctl.sweep;
+  const int done_total = h->ctl_host->sweep;
   if (tol_arg < 0.0 && done_total != total) return h->fail(RESNMTF_ERR_HIP, "sweep counter mismatch");
   if (all_err && done_total > 0) {
-    std::vector<double> host_err((size_t)done_total * h->V);
-    HIP_TRY(h, hipMemcpy(host_err.data(), h->err, host_err.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int t = 0; t < done_total; ++t) {        // mean over views (R/main.r:77-78,104-107)
       double sum = 0.0;
-      for (int v = 0; v < h->V; ++v) sum += host_err[(size_t)t * h->V + v];
+      for (int v = 0; v < h->V; ++v) sum += h->err_host[(size_t)t * h->V + v];
       all_err[t] = sum / (double)h->V;
     }
   }
   if (h->opt.time_kernels)
     if (int rc = flush_timing(h)) return rc;
   if (iters_done) *iters_done = done_total;
+  h->resume_ok = true;
   return RESNMTF_OK;
 }
 
