@@ -16,7 +16,9 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <random>
@@ -57,8 +59,10 @@ struct ViewState {
   double* xnorm2 = nullptr;
   double *F = nullptr, *G = nullptr, *S = nullptr, *lambda = nullptr, *mu = nullptr;
   float *F32 = nullptr, *G32 = nullptr, *T32 = nullptr;
+  unsigned short *Fk = nullptr, *Gk = nullptr;   // k > 16: K-packed bf16 pieces of F / G (B operands of pass_body_k32)
   int nsplit_xg = 1, rps_xg = 64, nw_xg = 4, nsaux_xg = 1, rpsaux_xg = 64;
   int nsplit_xtf = 1, rps_xtf = 64, nw_xtf = 4, nsaux_xtf = 1, rpsaux_xtf = 64;
+  int tw_xg = 8, tw_xtf = 8;         // k > 16 (wide form): 64-column tiles per workgroup
   float *Pxg = nullptr, *Pxtf = nullptr, *Paux_xg = nullptr, *Paux_xtf = nullptr;
   int *cnt_xg = nullptr, *cnt_xtf = nullptr;
   int rpbF = 16, nblkF = 1, rpbG = 16, nblkG = 1;
@@ -100,6 +104,9 @@ struct resnmtf_handle {
   std::vector<std::pair<int, hipGraphExec_t>> ladder;      // (sweeps, executable), descending
   double graph_tol = -2.0;
   bool resume_ok = false;             // the device state is exactly what the run prologue would produce: skip it
+  bool ctl_clean = false;             // ... and the loop control needs no reset either (fixed sweeps after fixed sweeps):
+  int sweep_base = 0;                 //     the device's sweep counter then simply runs on: value at the START of the
+  int next_base = 0;                  //     latest run / at its end
   SweepCtl* ctl_host = nullptr;       // pinned, device-mapped mirrors written by the k x k job of a sweep's last view /
   double* err_host = nullptr;         //   every view (fixed-iteration runs end with one stream synchronisation, no copy)
   SweepCtl* ctl_host_dev = nullptr;
@@ -144,7 +151,7 @@ hipError_t dev_alloc_zero(T** p, size_t count) {
 
 void free_view(ViewState& v) {
   if (v.fblk) { v.fblk = nullptr; v.Usum = nullptr; v.Ma_F = nullptr; v.Md_F = nullptr; v.lambda = nullptr; }   // arena slices
-  void* ptrs[] = {v.X16, v.Xt16, v.X32, v.Xt32, v.xnorm2, v.F, v.G, v.S, v.lambda, v.mu, v.F32, v.G32, v.T32, v.Pxg, v.Pxtf,
+  void* ptrs[] = {v.Fk, v.Gk, v.X16, v.Xt16, v.X32, v.Xt32, v.xnorm2, v.F, v.G, v.S, v.lambda, v.mu, v.F32, v.G32, v.T32, v.Pxg, v.Pxtf,
                   v.Paux_xg, v.Paux_xtf, v.cnt_xg, v.cnt_xtf, v.partF, v.partG, v.FtF, v.FtFS, v.cF, v.Ma_F, v.Md_F, v.Ma_G, v.Md_G};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -178,21 +185,18 @@ size_t update_smem_bytes(int KP) {
 }
 size_t kk_smem_bytes(int KP, int NW) { return sizeof(double) * ((size_t)4 * KP * KP + 3 * 64 * (size_t)NW); }
 size_t pass_smem_bytes(int KP, int NW) {
-  return std::max(sizeof(float) * (size_t)std::max(NW / 2, 1) * 64 * KP, kk_smem_bytes(KP, NW));
+  const size_t tile_form = std::max(sizeof(float) * (size_t)std::max(NW / 2, 1) * 64 * KP, kk_smem_bytes(KP, NW));
+  return KP > 16 ? std::max(tile_form, wide_smem_bytes(KP / 16)) : tile_form;
 }
 constexpr int kMaxLds = 160 * 1024;
 
 template <int NT, int NW, int UNROLL>
 hipError_t set_pass_attr() {
-  constexpr int S2 = NT >= 2 ? 2 : 0, S3 = NT >= 2 ? 3 : 0;      // (NT = 1 has no bf16 forms: the lists coincide)
-  const void* fns[12] = {reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, false>),
+  constexpr int S3 = NT >= 2 ? 3 : 0;      // (NT = 1 has no bf16 form: the lists coincide)
+  const void* fns[8] = {reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, false>),
                          reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, false>),
                          reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, true>),
                          reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, true>),
-                         reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, false, S2>),
-                         reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, false, S2>),
-                         reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, true, S2>),
-                         reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, true, S2>),
                          reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, false, S3>),
                          reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, true, false, S3>),
                          reinterpret_cast<const void*>(&pass_kernel<NT, NW, UNROLL, false, true, S3>),
@@ -263,15 +267,16 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
   a.kk_block0 = (v.kk_mode == 0) ? 1 : 0;
   if (!a.kk_block0) { kf.part = nullptr; ks.part = nullptr; }
   const int nw = xg ? v.nw_xg : v.nw_xtf;
-  const dim3 grid(a.kk_block0 ? 1 + a.ntiles * a.nsplit : a.naux * a.nsplit_aux + a.ntiles * a.nsplit), block(64 * nw);
+  // MFMA form of the main tiles (resnmtf_options.bf16_split): k <= 16 always the f32 MFMA; k > 16: three bf16 pieces per
+  // operand on the K = 32 MFMA in wide workgroups (f32-grade, default; 1 is accepted as an alias), 2 = plain f32 MFMA
+  const int split = v.NT < 2 ? 0 : (h->opt.bf16_split == 2 ? 0 : 3);
+  const int main_blocks = split == 3 ? a.ntg * a.nsplit : a.ntiles * a.nsplit;
+  const dim3 grid(a.kk_block0 ? 1 + main_blocks : a.naux * a.nsplit_aux + main_blocks), block(64 * nw);
   const size_t smem = std::min<size_t>(pass_smem_bytes(v.KP, nw) + (size_t)h->opt.pass_lds_pad_kb * 1024, kMaxLds);
   // timed mode: the start/stop events are attached to the dispatch itself (hipExtLaunchKernelGGL), so
   // the elapsed time is the kernel's own begin->end, the same quantity rocprofv3 --kernel-trace reports
   const bool timed = h->opt.time_kernels && h->ev_used + 2 <= h->ev.size();
   hipEvent_t ev0 = timed ? h->ev[h->ev_used] : nullptr, ev1 = timed ? h->ev[h->ev_used + 1] : nullptr;
-  // MFMA form of the main tiles (resnmtf_options.bf16_split): k <= 16 always the f32 MFMA; k > 16: 0 =
-  // three-piece bf16 split (f32-grade, default), 1 = two-piece (16-bit mantissa, fastest), 2 = plain f32
-  const int split = v.NT < 2 ? 0 : (h->opt.bf16_split == 1 ? 2 : (h->opt.bf16_split == 2 ? 0 : 3));
   if (v.half) {       // fp16 image of X: the run-time scale (set at upload) is taken out in the slab store
     a.out_scale = v.u16 ? 1.f / v.xscale : 1.f / (v.xscale * RESNMTF_B16_SCALE);
     // wave-steps per trip: 4 for fp16; 2 for the 16-bit integers (their widening to f32 wants the registers: c2 26.5 k
@@ -303,7 +308,6 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
   else hipLaunchKernelGGL((pass_kernel<NTV, NWV, UV, XG, MA, SP>), grid, block, smem, h->stream, a, kf, ks)
 #define LAUNCH_PASS_M(NTV, NWV, UV, XG, MA)                                              \
   if (split == 3) { LAUNCH_PASS_B(NTV, NWV, UV, XG, MA, ((NTV) >= 2 ? 3 : 0)); }         \
-  else if (split == 2) { LAUNCH_PASS_B(NTV, NWV, UV, XG, MA, ((NTV) >= 2 ? 2 : 0)); }    \
   else { LAUNCH_PASS_B(NTV, NWV, UV, XG, MA, 0); }
 #define LAUNCH_PASS(NTV, NWV, UV)                                   \
   if (xg && a.kk_block0) { LAUNCH_PASS_M(NTV, NWV, UV, true, true); }      \
@@ -535,15 +539,17 @@ void size_pass(int NT, int ntiles, int rows_pad, int slots, int max_nw, int forc
   // streamed geometry: 16-step workgroups (512 rows); for k > 32 only about 8 workgroups per slot, i.e.
   // longer splits -- there the per-workgroup epilogue (tree sum of 64 accumulator registers per lane +
   // slab store) costs as much as several trips (c5 X.G pass: 744 -> 602 us; k <= 32 prefers short splits)
+  // k > 16 (pass_body_k32): a workgroup trip is 256 rows, so splits are whole trips where the extent allows
+  const int gran = NT >= 2 ? quantum : 64;
   int r = 2 * quantum;
   if (NT >= 3) {
     const int ns_stream = std::max(1, std::min(16, ceil_div(8 * (slots + 1), std::max(ntiles, 1))));
-    r = std::max(r, round_up(ceil_div(rows_pad, ns_stream), 64));
+    r = std::max(r, round_up(ceil_div(rows_pad, ns_stream), gran));
   }
   if (ceil_div(rows_pad, r) > 16) r = round_up(ceil_div(rows_pad, 16), quantum);
   const int ns_one = std::min(16, slots / std::max(ntiles, 1));
   if (ns_one >= 1) {
-    const int r_one = round_up(ceil_div(rows_pad, ns_one), 64);
+    const int r_one = round_up(ceil_div(rows_pad, ns_one), gran);
     if (r_one <= 2048 && r_one >= quantum) r = r_one;
   }
   if (force_ns > 0) r = round_up(ceil_div(rows_pad, force_ns), 64);
@@ -552,11 +558,78 @@ void size_pass(int NT, int ntiles, int rows_pad, int slots, int max_nw, int forc
   *nsplit = ceil_div(rows_pad, r);
   *nw = w;
 }
-// aux workgroups: one unrolled trip each (so they finish early), at most 64 splits per aux tile
-void size_aux(int rows_pad, int nw, int* nsplit, int* rps) {
+// k > 16, wide form (pass_body_wide): a workgroup = TW tiles x 8 / TW row groups, one workgroup per CU.  Picks TW in
+// {8, 4} and the number of row splits (<= 16, the depth of the consumer's prefetch) so that the grid fills whole rounds
+// of the CUs -- 294 workgroups on 256 CUs cost a c5 X.G pass 468 us against 343 us with 490 (tools/micro/pass_k32_lab.hip)
+// -- preferring wide workgroups (the B block is read once per workgroup) and few splits (slab traffic).
+void size_aux(int rows_pad, int nw, int max_splits, int* nsplit, int* rps);
+// k > 16, wide form (pass_body_wide): a workgroup = TW tiles x 8 / TW row groups, one workgroup per CU.  Picks TW in
+// {8, 4}, the number of row splits (<= 16, the depth of the consumer's prefetch) and -- hand-off mode B -- the row splits
+// of the aux tiles by a small model of the launch: main workgroups of equal length dealt greedily to the CUs as they
+// become free, the aux workgroups (they head the grid) holding one CU each for t_aux and the k x k job one more for
+// t_kk behind the last of them.  What the model has to get right (tools/stamps.py, tools/micro/pass_k32_lab.hip on c5):
+//   * 294 main workgroups on 256 CUs are two rounds, the second almost empty: 468 us against 343 us with 490;
+//   * 32 aux workgroups of 45-100 us in front of 240 main ones: 16 main workgroups start that much later, and the one
+//     that gets the k x k job's CU started at 184 us and ended the launch at 442 us where the others ended at 320;
+//   * CUs that only ran an aux workgroup idle for the rest of a one-round launch.
+// Fewer splits mean less slab traffic (2 KP / rows of the X bytes per split) and fewer per-workgroup prologues.
+struct WidePlan { int tw = 8, nsplit = 1, rps = 64, nsaux = 1, rpsaux = 64; double makespan = 1e300; };
+// Workgroups are dealt round-robin to the 8 XCDs whatever their load (MI355X_MICROARCH.md, Workgroup dispatch): every XCD
+// serves ITS share of the grid with ITS 32 CUs, so the model is one XCD -- the one that also got the k x k job.
+double wide_makespan(int wgs, double d, int n_cu, int aux_wgs, double t_aux, double t_kk) {
+  const int cus = std::max(1, n_cu / 8), my_wgs = ceil_div(wgs, 8), my_aux = std::min(cus, ceil_div(aux_wgs, 8));
+  std::vector<double> free_at((size_t)cus, 0.0);
+  for (int c = 0; c < my_aux; ++c) free_at[(size_t)c] = (c == 0) ? t_aux + t_kk : t_aux;
+  double end = 0.0;
+  for (int w = 0; w < my_wgs; ++w) {
+    size_t cu = 0;
+    for (size_t c = 1; c < free_at.size(); ++c)
+      if (free_at[c] < free_at[cu]) cu = c;
+    free_at[cu] += d;
+    end = std::max(end, free_at[cu]);
+  }
+  // (the estimate of the main tiles is pessimistic for views that partly fit the Infinity Cache: keep the aux + k x k
+  // path well inside it)
+  return std::max(end, aux_wgs > 0 ? 1.5 * (t_aux + t_kk) : 0.0);
+}
+WidePlan plan_wide(int ntiles, int rows_pad, int KP, int kinds /* aux products, 0 = hand-off mode A */, int n_cu, int force_ns, int nw) {
+  const double t_pass = 4.0 * ntiles * 64.0 * rows_pad / 5.0e6;          // us for the X bytes at 5 TB/s
+  const double t_kk = 12.0 + 130.0 * (KP / 64.0) * (KP / 64.0) * (KP / 64.0);
+  WidePlan best;
+  int last_na = -1;
+  for (int want : {1, 2, 3, 4, 5, 6, 8, 10, 12, 16}) {
+    int na = 1, ra = 64;
+    size_aux(rows_pad, nw, want, &na, &ra);
+    if (kinds > 0 && na == last_na) continue;
+    last_na = na;
+    const int aux_wgs = kinds > 0 ? kinds * na : 1;                       // mode A: workgroup 0 is the k x k job
+    const double t_aux = kinds > 0 ? 2.0 * 256.0 * ra / 25.0e3 + 5.0 : 0.0;   // both operands at one CU's ~25 GB/s share
+    if (aux_wgs > n_cu / 2) break;
+    for (int tw : {8, 4}) {
+      const int trip = 32 * (8 / tw), ntg = ceil_div(ntiles, tw);
+      for (int ns = 1; ns <= 16; ++ns) {
+        if (force_ns > 0 && ns != force_ns) continue;
+        const int r = round_up(ceil_div(rows_pad, ns), trip);
+        const int ns_real = ceil_div(rows_pad, r);
+        if (ns_real != ns && force_ns <= 0) continue;                     // (a shorter list of splits is scored under its own count)
+        const int wgs = ntg * ns_real;
+        const double work = t_pass * n_cu * (1.0 + ns_real * 2.0 * KP / rows_pad) * (tw == 8 ? 1.0 : 1.03);   // CU us
+        const double d = work / wgs + 4.0;
+        const double ms = wide_makespan(wgs, d, n_cu, aux_wgs, t_aux, kinds > 0 ? t_kk : t_kk + 10.0);
+        if (ms < best.makespan) { best.makespan = ms; best.tw = tw; best.nsplit = ns_real; best.rps = r; best.nsaux = na; best.rpsaux = ra; }
+      }
+    }
+    if (kinds == 0) break;
+  }
+  return best;
+}
+// (wide form, k > 16: at most 16 -- the k x k job sums the slabs of every split while the pass saturates the memory
+// system, and with one workgroup per CU and one or two rounds of long main workgroups its CU is missing for as long as
+// it runs: c5 passes 409 / 486 us with 32 / 49 aux splits against 326 / 313 us for the main tiles alone)
+void size_aux(int rows_pad, int nw, int max_splits, int* nsplit, int* rps) {
   const int quantum = 4 * nw * 8;
   int r = quantum;
-  if (ceil_div(rows_pad, r) > 64) r = round_up(ceil_div(rows_pad, 64), quantum);
+  if (ceil_div(rows_pad, r) > max_splits) r = round_up(ceil_div(rows_pad, max_splits), quantum);
   r = std::min(r, round_up(rows_pad, 64));
   *rps = r;
   *nsplit = ceil_div(rows_pad, r);
@@ -730,8 +803,9 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     if (o.kk_mode == 2) vs.kk_mode = 1;
     // workgroup slots of a pass launch: target_workgroups overrides CUs x resident workgroups per CU
     const int nw_guess = (vs.NT <= 1 && (o.pass_waves == 4 || o.pass_waves == 8 || o.pass_waves == 16)) ? o.pass_waves : 8;
-    size_aux(vs.m_pad, nw_guess, &vs.nsaux_xg, &vs.rpsaux_xg);
-    size_aux(vs.n_pad, nw_guess, &vs.nsaux_xtf, &vs.rpsaux_xtf);
+    const int aux_cap = (vs.NT >= 2 && o.bf16_split != 2) ? 16 : 64;
+    size_aux(vs.m_pad, nw_guess, aux_cap, &vs.nsaux_xg, &vs.rpsaux_xg);
+    size_aux(vs.n_pad, nw_guess, aux_cap, &vs.nsaux_xtf, &vs.rpsaux_xtf);
     const int slots_all = o.target_workgroups > 0 ? o.target_workgroups : h->n_cu * pass_blocks_per_cu(vs.NT, nw_guess);
     const int slots_xg = slots_all - (vs.kk_mode == 0 ? 1 : 3 * vs.nsaux_xg);
     const int slots_xtf = slots_all - (vs.kk_mode == 0 ? 1 : 2 * vs.nsaux_xtf);
@@ -739,6 +813,13 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
               &vs.nsplit_xg, &vs.rps_xg, &vs.nw_xg);
     size_pass(vs.NT, vs.m_pad / 64, vs.n_pad, slots_xtf, max_pass_waves(vs.NT), o.pass_waves, o.pass_splits_xtf,
               &vs.nsplit_xtf, &vs.rps_xtf, &vs.nw_xtf);
+    if (vs.NT >= 2 && o.bf16_split != 2) {      // k > 16: the wide bf16-piece form
+      const WidePlan pg = plan_wide(vs.n_pad / 64, vs.m_pad, vs.KP, vs.kk_mode == 0 ? 0 : 3, slots_all, o.pass_splits_xg, nw_guess);
+      const WidePlan pf = plan_wide(vs.m_pad / 64, vs.n_pad, vs.KP, vs.kk_mode == 0 ? 0 : 2, slots_all, o.pass_splits_xtf, nw_guess);
+      vs.tw_xg = pg.tw; vs.nsplit_xg = pg.nsplit; vs.rps_xg = pg.rps;
+      vs.tw_xtf = pf.tw; vs.nsplit_xtf = pf.nsplit; vs.rps_xtf = pf.rps;
+      if (vs.kk_mode != 0) { vs.nsaux_xg = pg.nsaux; vs.rpsaux_xg = pg.rpsaux; vs.nsaux_xtf = pf.nsaux; vs.rpsaux_xtf = pf.rpsaux; }
+    }
     // k <= 16: when the workgroups of a pass outnumber the slots (streamed geometry) each wave keeps the next
     // trip's loads in flight while it multiplies (two buffers of 4 steps instead of one of 8): X.G pass of a
     // 40000 x 2000 view 74 -> 67 us.  With everything resident from t = 0 (c2) the plain form is faster.
@@ -793,6 +874,10 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     if ((e = dev_alloc_zero(&vs.F32, (size_t)vs.n_pad * 64)) != hipSuccess) return bail(e, "hipMalloc F32");
     if ((e = dev_alloc_zero(&vs.G32, (size_t)vs.m_pad * 64)) != hipSuccess) return bail(e, "hipMalloc G32");
     if ((e = dev_alloc_zero(&vs.T32, (size_t)vs.m_pad * 64)) != hipSuccess) return bail(e, "hipMalloc T32");
+    if (vs.NT >= 2) {
+      if ((e = dev_alloc_zero(&vs.Fk, (size_t)vs.n_pad * vs.KP * 3)) != hipSuccess) return bail(e, "hipMalloc Fk");
+      if ((e = dev_alloc_zero(&vs.Gk, (size_t)vs.m_pad * vs.KP * 3)) != hipSuccess) return bail(e, "hipMalloc Gk");
+    }
     if ((e = dev_alloc_zero(&vs.cnt_xg, 4)) != hipSuccess) return bail(e, "hipMalloc cnt");
     if ((e = dev_alloc_zero(&vs.cnt_xtf, 4)) != hipSuccess) return bail(e, "hipMalloc cnt");
     for (double** pp : {&vs.FtF, &vs.FtFS, &vs.Ma_G, &vs.Md_G})
@@ -889,9 +974,9 @@ int build_half_images(resnmtf_handle* h, ViewState& vs) {
       HIP_TRY(h, hipMemsetAsync(vs.F32, 0, (size_t)vs.n_pad * 64 * sizeof(float), h->stream));
       HIP_TRY(h, hipMemsetAsync(vs.G32, 0, (size_t)vs.m_pad * 64 * sizeof(float), h->stream));
       hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(vs.n * vs.k, 256)), dim3(256), 0, h->stream, vs.F, vs.n,
-                         vs.k, vs.F32, vs.kk_mode == 0 ? vs.KP : 64, vs.NT, vs.half ? 1 : 0);
+                         vs.k, vs.F32, vs.kk_mode == 0 ? vs.KP : 64, vs.NT, vs.half ? 1 : 0, vs.Fk);
       hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(vs.m * vs.k, 256)), dim3(256), 0, h->stream, vs.G, vs.m,
-                         vs.k, vs.G32, vs.kk_mode == 0 ? vs.KP : 64, vs.NT, vs.half ? 1 : 0);
+                         vs.k, vs.G32, vs.kk_mode == 0 ? vs.KP : 64, vs.NT, vs.half ? 1 : 0, vs.Gk);
       HIP_TRY(h, hipGetLastError());
       HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
@@ -1071,9 +1156,9 @@ int resnmtf_set_factors(resnmtf_handle* h, int v, const double* F, const double*
     HIP_TRY(h, hipMemsetAsync(vs.cnt_xg, 0, 4 * sizeof(int), h->stream));
     HIP_TRY(h, hipMemsetAsync(vs.cnt_xtf, 0, 4 * sizeof(int), h->stream));
     hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(vs.n * vs.k, 256)), dim3(256), 0, h->stream, vs.F, vs.n,
-                       vs.k, vs.F32, vs.kk_mode == 0 ? vs.KP : 64, vs.NT, vs.half ? 1 : 0);
+                       vs.k, vs.F32, vs.kk_mode == 0 ? vs.KP : 64, vs.NT, vs.half ? 1 : 0, vs.Fk);
     hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(vs.m * vs.k, 256)), dim3(256), 0, h->stream, vs.G, vs.m,
-                       vs.k, vs.G32, vs.kk_mode == 0 ? vs.KP : 64, vs.NT, vs.half ? 1 : 0);
+                       vs.k, vs.G32, vs.kk_mode == 0 ? vs.KP : 64, vs.NT, vs.half ? 1 : 0, vs.Gk);
     HIP_TRY(h, hipGetLastError());
   }
   HIP_TRY(h, hipStreamSynchronize(h->stream));   // host vectors go out of scope
@@ -1316,7 +1401,7 @@ int resnmtf_init_svd(resnmtf_handle* h, int v, unsigned long long seed, double s
   HIP_TRY(h, hipMemcpyAsync(sc.Zm, omega.data(), omega.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemsetAsync(vs.F32, 0, (size_t)vs.n_pad * 64 * sizeof(float), h->stream));
   HIP_TRY(h, hipMemsetAsync(vs.G32, 0, (size_t)vs.m_pad * 64 * sizeof(float), h->stream));
-  hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(m * L, 256)), dim3(256), 0, h->stream, sc.Zm, m, L, vs.G32, 64, NTi, 0);
+  hipLaunchKernelGGL(factor_to_f32_kernel, dim3(ceil_div(m * L, 256)), dim3(256), 0, h->stream, sc.Zm, m, L, vs.G32, 64, NTi, 0, (unsigned short*)nullptr);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   for (int it = 0; it < n_power; ++it) {
     launch_pass_plain(h, xg, NTi, true);                                                   // Y = X Z
@@ -1474,7 +1559,7 @@ static int build_args(resnmtf_handle* h) {
     // --- F update (R/update_steps.r:141-165)
     UpdateArgs& f = vs.argF;
     f = UpdateArgs{};
-    f.len = vs.n; f.k = vs.k; f.W = vs.F; f.W32 = vs.F32; f.ld32 = vs.kk_mode == 0 ? vs.KP : 64; f.kpack32 = vs.half ? 1 : 0;
+    f.len = vs.n; f.k = vs.k; f.W = vs.F; f.W32 = vs.F32; f.Wk = vs.Fk; f.ld32 = vs.kk_mode == 0 ? vs.KP : 64; f.kpack32 = vs.half ? 1 : 0;
     f.P = vs.Pxg; f.nsplit = vs.nsplit_xg; f.cols_pad = vs.n_pad;
     if (vs.Usum) { f.P = vs.Usum; f.nsplit = 1; }      // replicate_f: the folded slab of the exchange block
     f.Ma = vs.Ma_F; f.Md = vs.Md_F; f.lm = vs.lambda; f.T32 = nullptr; f.part = vs.partF;
@@ -1500,16 +1585,18 @@ static int build_args(resnmtf_handle* h) {
     // --- streaming passes
     PassArgs& xg = vs.passXG;
     xg = PassArgs{};
-    xg.A = vs.Xt32; xg.lda = 64; xg.tile_stride = vs.ldxt; xg.ntiles = vs.n_pad / 64; xg.B = vs.G32; xg.ldb = vs.kk_mode == 0 ? vs.KP : 64; xg.P = vs.Pxg;
+    xg.A = vs.Xt32; xg.lda = 64; xg.tile_stride = vs.ldxt; xg.ntiles = vs.n_pad / 64; xg.B = vs.G32; xg.Bk = vs.Gk; xg.ldb = vs.kk_mode == 0 ? vs.KP : 64; xg.P = vs.Pxg;
     xg.cols_pad = vs.n_pad; xg.rows_pad = vs.m_pad; xg.rows_per_split = vs.rps_xg; xg.nsplit = vs.nsplit_xg;
+    xg.tw = vs.tw_xg; xg.ntg = ceil_div(xg.ntiles, xg.tw);
     xg.A16 = vs.Xt16; xg.tile_stride16 = vs.ld16xt;
     xg.aux[0] = vs.G32; xg.aux[1] = vs.T32; xg.aux[2] = nullptr; xg.naux = 3;     // G^T G, T^T G, colSums(G)
     xg.Paux = vs.Paux_xg; xg.rows_per_split_aux = vs.rpsaux_xg; xg.nsplit_aux = vs.nsaux_xg; xg.aux_cnt = vs.cnt_xg;
     xg.ctl = h->ctl;
     PassArgs& xt = vs.passXtF;
     xt = PassArgs{};
-    xt.A = vs.X32; xt.lda = 64; xt.tile_stride = vs.ldx; xt.ntiles = vs.m_pad / 64; xt.B = vs.F32; xt.ldb = vs.kk_mode == 0 ? vs.KP : 64; xt.P = vs.Pxtf;
+    xt.A = vs.X32; xt.lda = 64; xt.tile_stride = vs.ldx; xt.ntiles = vs.m_pad / 64; xt.B = vs.F32; xt.Bk = vs.Fk; xt.ldb = vs.kk_mode == 0 ? vs.KP : 64; xt.P = vs.Pxtf;
     xt.cols_pad = vs.m_pad; xt.rows_pad = vs.n_pad; xt.rows_per_split = vs.rps_xtf; xt.nsplit = vs.nsplit_xtf;
+    xt.tw = vs.tw_xtf; xt.ntg = ceil_div(xt.ntiles, xt.tw);
     xt.A16 = vs.X16; xt.tile_stride16 = vs.ld16x;
     xt.aux[0] = vs.F32; xt.aux[1] = nullptr; xt.naux = 2;                          // F^T F, colSums(F)
     xt.Paux = vs.Paux_xtf; xt.rows_per_split_aux = vs.rpsaux_xtf; xt.nsplit_aux = vs.nsaux_xtf; xt.aux_cnt = vs.cnt_xtf;
@@ -1517,7 +1604,7 @@ static int build_args(resnmtf_handle* h) {
     // --- G update (R/update_steps.r:180-207); branch on the WHOLE psi matrix (:190)
     UpdateArgs& g = vs.argG;
     g = UpdateArgs{};
-    g.len = vs.m; g.k = vs.k; g.W = vs.G; g.W32 = vs.G32; g.ld32 = vs.kk_mode == 0 ? vs.KP : 64; g.kpack32 = vs.half ? 1 : 0;
+    g.len = vs.m; g.k = vs.k; g.W = vs.G; g.W32 = vs.G32; g.Wk = vs.Gk; g.ld32 = vs.kk_mode == 0 ? vs.KP : 64; g.kpack32 = vs.half ? 1 : 0;
     g.P = vs.Pxtf; g.nsplit = vs.nsplit_xtf; g.cols_pad = vs.m_pad;
     g.Ma = vs.Ma_G; g.Md = vs.Md_G; g.lm = vs.mu; g.T32 = vs.T32; g.part = vs.partG;
     g.rows_per_block = vs.rpbG; g.ctl = h->ctl;
@@ -1581,15 +1668,21 @@ int resnmtf_reserve_sweeps(resnmtf_handle* h, int sweeps) {
 // allow_resume: resnmtf_run directly after a completed resnmtf_run with nothing set in between -- the device state
 // (X.G slabs, F coefficients, Gram partials) is bit for bit what the run prologue would recompute, so only the loop
 // control is reset, in stream order, without a host synchronisation
-static int prepare_impl(resnmtf_handle* h, bool allow_resume) {
+static int prepare_impl(resnmtf_handle* h, bool allow_resume, bool keep_ctl = false) {
   if (!h->prepared) {
     destroy_graphs(h);
     if (int rc = build_args(h)) return rc;
     h->prepared = true;
   }
+  const bool resume = allow_resume && h->resume_ok;
+  if (resume && keep_ctl && h->ctl_clean && h->next_base < (1 << 30)) {      // not even a memset
+    h->sweep_base = h->next_base;
+    return RESNMTF_OK;
+  }
+  h->sweep_base = h->next_base = 0;
   std::memset(h->ctl_host, 0, sizeof(SweepCtl));
   HIP_TRY(h, hipMemsetAsync(h->ctl, 0, sizeof(SweepCtl), h->stream));      // all-zero bytes = SweepCtl{}
-  if (allow_resume && h->resume_ok) return RESNMTF_OK;
+  if (resume) return RESNMTF_OK;
   // run prologue: F coefficients and the first X.G pass of every owned view
   h->resume_ok = false;
   for (const auto& v : h->views)
@@ -1648,9 +1741,17 @@ int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, doubl
     if (all_err) total = std::min(total, err_capacity);
     if (total < 1) return h->fail(RESNMTF_ERR_INVALID, "convergence mode needs max_iters > 0 or an all_err buffer");
   }
+  // RESNMTF_TRACE_RUN=1: host-side stage times of this call on stderr (diagnostic, tools/time_run_overhead.py)
+  static const bool trace = std::getenv("RESNMTF_TRACE_RUN") != nullptr;
+  using clk = std::chrono::steady_clock;
+  clk::time_point tp[6];
+  if (trace) tp[0] = clk::now();
   if (int rc = ensure_err_capacity(h, total)) return rc;
   // (the host mirror of the loop control is rewritten below: the previous run has been waited for)
-  if (int rc = prepare_impl(h, true)) return rc;
+  if (int rc = prepare_impl(h, true, tol_arg < 0.0)) return rc;
+  const int base = h->sweep_base;      // sweeps the device counter stood at when this run began
+  h->ctl_clean = false;
+  if (trace) tp[1] = clk::now();
   h->resume_ok = false;
   const bool eager = !h->opt.use_graph || h->opt.time_kernels;
   const int batch = std::max(1, h->opt.check_every);
@@ -1681,13 +1782,16 @@ int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, doubl
     }
   }
   HIP_TRY(h, hipGetLastError());
+  if (trace) tp[2] = clk::now();
   if (int rc = sync_both(h)) return rc;
-  const int done_total = h->ctl_host->sweep;
+  if (trace) tp[3] = clk::now();
+  const int done_total = h->ctl_host->sweep - base;
   if (tol_arg < 0.0 && done_total != total) return h->fail(RESNMTF_ERR_HIP, "sweep counter mismatch");
   if (all_err && done_total > 0) {
     for (int t = 0; t < done_total; ++t) {        // mean over views (R/main.r:77-78,104-107)
       double sum = 0.0;
-      for (int v = 0; v < h->V; ++v) sum += h->err_host[(size_t)t * h->V + v];
+      const size_t row = (size_t)((base + t) % h->err_cap) * h->V;
+      for (int v = 0; v < h->V; ++v) sum += h->err_host[row + v];
       all_err[t] = sum / (double)h->V;
     }
   }
@@ -1695,6 +1799,14 @@ int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, doubl
     if (int rc = flush_timing(h)) return rc;
   if (iters_done) *iters_done = done_total;
   h->resume_ok = true;
+  h->ctl_clean = tol_arg < 0.0;        // (a convergence run leaves its stop flag and prev_mean behind)
+  h->next_base = base + done_total;
+  if (trace) {
+    tp[4] = clk::now();
+    auto us = [&](int a, int b) { return std::chrono::duration<double, std::micro>(tp[b] - tp[a]).count(); };
+    std::fprintf(stderr, "[resnmtf_run] sweeps %d: prepare %.1f us, enqueue %.1f us, wait %.1f us, read-out %.1f us\n", total,
+                 us(0, 1), us(1, 2), us(2, 3), us(3, 4));
+  }
   return RESNMTF_OK;
 }
 
@@ -1774,10 +1886,11 @@ int resnmtf_view_errors(resnmtf_handle* h, int v, int first, int count, double* 
   if (first + count > h->err_cap) return h->fail(RESNMTF_ERR_INVALID, "range beyond the reserved error buffer");
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
   if (int rc = sync_both(h)) return rc;
-  std::vector<double> buf((size_t)count * h->V);
+  // (sweep t of the latest run / of the phases since resnmtf_prepare sits in row (base + t) mod capacity)
+  std::vector<double> buf((size_t)h->err_cap * h->V);
   if (count > 0)
-    HIP_TRY(h, hipMemcpy(buf.data(), h->err + (size_t)first * h->V, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
-  for (int t = 0; t < count; ++t) out[t] = buf[(size_t)t * h->V + v];
+    HIP_TRY(h, hipMemcpy(buf.data(), h->err, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int t = 0; t < count; ++t) out[t] = buf[(size_t)((h->sweep_base + first + t) % h->err_cap) * h->V + v];
   return RESNMTF_OK;
 }
 
@@ -1791,6 +1904,10 @@ int resnmtf_synchronize(resnmtf_handle* h) {
 // diagnostic build only: point the stamp buffer at `buf` ([blocks][16] u64) or detach it (NULL)
 int resnmtf_debug_set_stamp_buffer(unsigned long long* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : RESNMTF_ERR_HIP;
+}
+// 1 = only the pass launches stamp, 2 = only the update kernels, 3 = both (they share the columns)
+int resnmtf_debug_set_stamp_select(int sel) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sel), &sel, sizeof(sel)) == hipSuccess ? 0 : RESNMTF_ERR_HIP;
 }
 #endif
 

@@ -44,6 +44,7 @@ buf = torch.zeros((nblk, 16), dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
 e.phase(0, _lib.PHASE_F, 3); e.synchronize()
 assert lib.resnmtf_debug_set_stamp_buffer(C.c_void_p(buf.data_ptr())) == 0
+assert lib.resnmtf_debug_set_stamp_select(1) == 0      # the G update between the two passes shares their columns
 e.phase(0, _lib.PHASE_G, 3); e.synchronize()
 lib.resnmtf_debug_set_stamp_buffer(None)
 tall = buf.cpu().numpy().astype(np.int64)
@@ -70,12 +71,15 @@ for name, base in (("Xt.F", 8), ("X.G", 0)):
     # concurrency profile: how many main workgroups are alive at each microsecond
     ent, end = us(main[:, 0]), us(main[:, 1])
     prof = [int(((ent <= x) & (end > x)).sum()) for x in np.arange(0, end.max() + 1, 1.0)]
-    print("  alive main WGs per us:", prof)
+    step = max(1, len(prof) // 60)
+    print(f"  alive main WGs every {step} us:", prof[::step])
     # structure of the spread: mean end time by XCD (dispatch order round-robins workgroups over the
     # 8 XCDs), by tile and by split
     ids = np.nonzero((tall[:, base] > 0) & (tall[:, base + 1] > 0) & (tall[:, base + 2] == 0))[0]
     endt = (tall[ids, base + 1] - t0) / 100.0
     nt = (m + 63) // 64 if name == "Xt.F" else (n + 63) // 64
+    if prob.k > 16:                      # wide form: tile GROUPS of 8 (or 4) tiles
+        nt = (nt + 7) // 8
     off = ids.min()                      # first main block
     tile, split = (ids - off) % nt, (ids - off) // nt
     print("  mean end by XCD (block % 8):", np.round([endt[ids % 8 == x].mean() for x in range(8)], 1))
