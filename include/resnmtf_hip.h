@@ -166,11 +166,14 @@ int resnmtf_set_view_raw(resnmtf_handle* h, int v, const double* x_raw, int* was
  *                         pseudo-randomly on the device (Feistel network with cycle walking, `seed`), then
  *                         -- normalise != 0 -- non-negativity shift + column normalisation as apply_resnmtf
  *                         applies to the shuffled data (R/obtain_bicl.r:35 -> R/utils.r:416,422).  R's own
- *                         sample() stream cannot be reproduced; positive data never yields an empty row or
- *                         column, so the reference's redraw loop (:14-18) has nothing to do;
+ *                         sample() stream cannot be reproduced.  The reference redraws while a row or a column
+ *                         of the shuffled matrix sums to zero (:14-18): resnmtf_view_empty_lines reports that
+ *                         condition for the draw just made, the caller redraws with another seed;
  *   resnmtf_subsample_view  the sub-sample X[rows, cols] of stability_repeat (R/stability_analysis.r:230-249; dst's
  *                         shape = the index counts; 0-based indices into the source view), NOT re-normalised,
- *                         exactly as the reference factorises it;
+ *                         exactly as the reference factorises it; all-zero rows / columns
+ *                         of the sub-sample (the reference drops them, R/stability_analysis.r:165-190, :233-240)
+ *                         are reported by resnmtf_view_empty_lines, masks included;
  *   resnmtf_get_view      the device copy back as fp64 column-major (fp32 precision), e.g. for a host-side
  *                         SVD or for tests.
  */
@@ -178,6 +181,11 @@ int resnmtf_copy_view(resnmtf_handle* dst, int v, resnmtf_handle* src, int v_src
 int resnmtf_shuffle_view(resnmtf_handle* dst, int v, resnmtf_handle* src, int v_src, unsigned long long seed,
                          int normalise);
 int resnmtf_subsample_view(resnmtf_handle* dst, int v, resnmtf_handle* src, int v_src, const int* rows, const int* cols);
+/* Rows / columns of view v's data that summed to exactly zero when it was last drawn on the device
+ * (resnmtf_shuffle_view, resnmtf_subsample_view; before any shift / normalisation): counts, and -- if not NULL --
+ * 0 / 1 masks of length n and m.  Zero after a host upload (the host has the data). */
+int resnmtf_view_empty_lines(resnmtf_handle* h, int v, int* n_empty_rows, int* n_empty_cols, unsigned char* row_mask,
+                             unsigned char* col_mask);
 int resnmtf_get_view(resnmtf_handle* h, int v, double* x);
 
 /*

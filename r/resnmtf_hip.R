@@ -48,29 +48,19 @@ res_nmtf_inner_hip <- function(
   for (v in seq_len(n_v)) {                                                  # R/update_steps.r:57-60
     rownames(res$output_f[[v]]) <- rownames(data[[v]])
     rownames(res$output_g[[v]]) <- colnames(data[[v]])
-    rownames(res$row_clusters[[v]]) <- rownames(data[[v]])                   # R/obtain_bicl.r:166,171
-    rownames(res$col_clusters[[v]]) <- colnames(data[[v]])
   }
   if (no_clusts) {                                                           # R/main.r:115-120
     return(list(output_f = res$output_f, output_s = res$output_s, output_g = res$output_g))
   }
-  row_cl <- res$row_clusters
-  col_cl <- res$col_clusters
-  bisil <- c()
-  biclusts <- if (spurious) check_biclusters(data, res$output_f, num_repeats) else NULL   # stays in R
-  for (i in seq_len(n_v)) {                                                  # R/obtain_bicl.r:178-196
-    relations <- apply(res$output_s[[i]], 2, which.max)
-    if (spurious) {
-      indices <- ((biclusts$score[i, ]) < biclusts$max_threshold[i]) | ((biclusts$score[i, ]) == 0)
-      new_indices <- indices[relations]
-      row_cl[[i]][, new_indices] <- 0
-      col_cl[[i]][, new_indices] <- 0
-    }
-    bisil <- c(bisil, bisilhouette::bisilhouette(data[[i]], row_cl[[i]], col_cl[[i]], method = distance)$bisil)
-  }
-  bisil <- ifelse(sum(bisil) == 0, 0, mean(bisil[bisil != 0]))
-  error <- if (is.null(n_iters)) mean(utils::tail(res$All_Error, n = 10)) else utils::tail(res$All_Error, n = 1)
+  # From here on the package's own code runs unchanged on the returned (normalised) factors: obtain_biclusters
+  # (R/main.r:122-125 -> R/obtain_bicl.r:151-204) thresholds F > 1/n, G > 1/m, pairs through which.max of S, removes
+  # spurious biclusters and scores with bisilhouette -- nothing of it is restated here.  (res$row_clusters /
+  # res$col_clusters, the device's thresholded matrices, equal what it computes for spurious = FALSE and are only
+  # of use to callers that skip it, e.g. the stability repeats.)
+  clusters <- obtain_biclusters(data, res$output_f, res$output_g, res$output_s, num_repeats, spurious, distance)
+  error <- if (is.null(n_iters)) mean(utils::tail(res$All_Error, n = 10)) else utils::tail(res$All_Error, n = 1)   # R/main.r:126-130
   list(output_f = res$output_f, output_s = res$output_s, output_g = res$output_g,
-       Error = error, All_Error = res$All_Error, bisil = bisil,
-       row_clusters = row_cl, col_clusters = col_cl, lambda = res$lambda, mu = res$mu)
+       Error = error, All_Error = res$All_Error, bisil = clusters$bisil,
+       row_clusters = clusters$row_clustering, col_clusters = clusters$col_clustering,
+       lambda = res$lambda, mu = res$mu)                                     # R/main.r:131-139
 }

@@ -62,6 +62,7 @@ SIGNATURES = {
     "resnmtf_copy_view": (C.c_int, [_h, C.c_int, _h, C.c_int]),
     "resnmtf_shuffle_view": (C.c_int, [_h, C.c_int, _h, C.c_int, C.c_ulonglong, C.c_int]),
     "resnmtf_subsample_view": (C.c_int, [_h, C.c_int, _h, C.c_int, _ip, _ip]),
+    "resnmtf_view_empty_lines": (C.c_int, [_h, C.c_int, _ip, _ip, C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]),
     "resnmtf_get_view": (C.c_int, [_h, C.c_int, _dp]),
     "resnmtf_set_factors": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "resnmtf_init_svd": (C.c_int, [_h, C.c_int, C.c_ulonglong, C.c_double, C.c_int, _dp]),

@@ -77,7 +77,7 @@ def res_nmtf_inner(data, row_indices, column_indices,
                    n_iters=None, num_repeats=5, spurious=True, distance="euclidean",
                    no_clusts=False, *, row_names=None, col_names=None, device_id: int = 0,
                    max_iters: int = 100000, seed: Optional[int] = None, engine_opts: Optional[dict] = None,
-                   host_init: bool = False):
+                   host_init: bool = False, return_init: bool = False):
     """``res_nmtf_inner`` (``R/main.r:32-140``).
 
     ``data``: list of pre-processed (non-negative, column-normalised) matrices; ``row_indices[v][w]``
@@ -88,7 +88,8 @@ def res_nmtf_inner(data, row_indices, column_indices,
     the matrices' dimnames), ``max_iters`` (a guard the reference lacks), ``seed`` for the SVD
     init noise, ``host_init`` (without explicit initial factors: ``False`` = ``init_mats_inner`` on
     the device, randomized top-k SVD on the pass kernels, milliseconds; ``True`` = NumPy's full SVD
-    on the host as the reference's ``svd()``, seconds to minutes -- statistically equivalent).
+    on the host as the reference's ``svd()``, seconds to minutes -- statistically equivalent),
+    ``return_init`` (adds ``"init"``: the (F, S, G, lambda, mu) per view the loop started from).
     """
     data = [np.asarray(d, dtype=np.float64) for d in _as_list(data)]
     n_v = len(data)
@@ -128,6 +129,7 @@ def res_nmtf_inner(data, row_indices, column_indices,
     try:
         _load_engine(eng, data, init_f, init_s, init_g, lam, mu, phi, xi, psi,
                      row_names, col_names, row_indices, column_indices, seed=seed)
+        init_state = [eng.get_factors(v) for v in range(n_v)] if return_init else None      # (F, S, G, lambda, mu) the loop starts from
         total_err = eng.run(n_iters=n_iters, tol=1.0e-6, max_iters=max_iters)
         out_f, out_s, out_g, row_cl, col_cl, lams, mus = [], [], [], [], [], [], []
         for v in range(n_v):
@@ -138,18 +140,24 @@ def res_nmtf_inner(data, row_indices, column_indices,
     finally:
         eng.close()
     if no_clusts:                                                                                 # main.r:115-120
-        return {"output_f": out_f, "output_s": out_s, "output_g": out_g}
+        res = {"output_f": out_f, "output_s": out_s, "output_g": out_g}
+        if return_init:
+            res["init"] = init_state
+        return res
     if n_iters is None:
         error = float(np.mean(total_err[-10:]))                                                   # main.r:127
     else:
         error = float(total_err[-1])                                                              # main.r:129
-    return {
+    res = {
         "output_f": out_f, "output_s": out_s, "output_g": out_g,
         "Error": error, "All_Error": total_err,
         "bisil": None,            # bisilhouette::bisilhouette is not available offline
         "row_clusters": row_cl, "col_clusters": col_cl,
         "lambda": lams, "mu": mus,
     }
+    if return_init:               # (test hook: the initial state the device built, for a reference run from the same start)
+        res["init"] = init_state
+    return res
 
 
 def apply_resnmtf(data, init_f=None, init_s=None, init_g=None, k_val=None,

@@ -138,7 +138,7 @@ def stability_jobs(data, k: int, n_stability: int = 5, sample_rate: float = 0.9,
 # ---------------------------------------------------------------------------------------------
 # execution
 # ---------------------------------------------------------------------------------------------
-def run_job(job: Job, device_id: int = 0, pre_processed: bool = False) -> dict:
+def run_job(job: Job, device_id: int = 0, pre_processed: bool = False, return_init: bool = False) -> dict:
     """One factorisation through the accelerated path: naming, symmetrisation and (unless
     ``pre_processed``) non-negativity shift + normalisation as ``apply_resnmtf`` does, device-side SVD
     initialisation, the loop, finalise."""
@@ -152,7 +152,7 @@ def run_job(job: Job, device_id: int = 0, pre_processed: bool = False) -> dict:
         data = naming.check_data(data)
     res = api.res_nmtf_inner(data, row_idx, col_idx, None, None, None, [job.k_val] * n_v, phi, xi, psi,
                              job.n_iters, spurious=False, row_names=rn, col_names=cn, device_id=device_id,
-                             seed=job.seed)
+                             seed=job.seed, return_init=return_init)
     res["tag"] = job.tag
     res["extras"] = job.extras
     return res
@@ -205,15 +205,56 @@ class DeviceData:
     def close(self):
         self.base.close()
 
+    def _trim_samples(self, samples, max_rounds: int = 20):
+        """``sample_view`` / ``stability_repeat`` (``R/stability_analysis.r:165-190``, ``:233-240``): all-zero rows and
+        columns of a sub-sample are dropped -- from every earlier view that shares the draw (equal extent along that
+        axis) -- and the sub-samples gathered again, until none is left.  The emptiness test runs on the device
+        (``resnmtf_view_empty_lines``), on probes that hold only the data.  Returns the trimmed draws or ``None``."""
+        from .engine import Engine
+        n_v = len(self.data_shapes)
+        rows = [np.asarray(r).copy() for r in samples[0]]; cols = [np.asarray(c).copy() for c in samples[1]]
+        for _ in range(max_rounds):
+            changed = False
+            for i in range(n_v):
+                if len(rows[i]) < 2 or len(cols[i]) < 2:
+                    return None
+                probe = Engine([len(rows[i])], [len(cols[i])], [2], device_id=self.device_id)
+                try:
+                    probe.subsample_view_from(0, self.base, i, rows[i], cols[i])
+                    er, ec = probe.empty_lines(0)
+                finally:
+                    probe.close()
+                if er.any() or ec.any():
+                    changed = True
+                    same_r = self.data_shapes[i][0] == self.data_shapes[0][0]
+                    same_c = self.data_shapes[i][1] == self.data_shapes[0][1]
+                    for p in (range(i + 1) if same_r else [i]):            # :168-174
+                        if len(rows[p]) == len(er):
+                            rows[p] = rows[p][~er]
+                    for p in (range(i + 1) if same_c else [i]):            # :175-181
+                        if len(cols[p]) == len(ec):
+                            cols[p] = cols[p][~ec]
+            if not changed:
+                return rows, cols
+        return None
+
     def factorise(self, k: int, n_iters: Optional[int] = None, seed: int = 0, shuffle_seed: Optional[int] = None,
-                  max_iters: int = 100000, tag: str = "", samples=None) -> dict:
+                  max_iters: int = 100000, tag: str = "", samples=None, return_init: bool = False,
+                  return_data: bool = False) -> dict:
         """One factorisation with k biclusters per view: views copied -- or, with ``shuffle_seed``, shuffled as
-        ``obtain_shuffled_f`` does (no restrictions, fresh names), or, with ``samples = (row_samples,
-        col_samples)``, sub-sampled as ``stability_repeat`` does (not re-normalised, names carried over) --
-        on the device, device SVD init, loop, finalise."""
+        ``obtain_shuffled_f`` does (no restrictions, fresh names; redrawn while a row or a column of the shuffled
+        matrix sums to zero, ``R/obtain_bicl.r:14-18``), or, with ``samples = (row_samples, col_samples)``,
+        sub-sampled as ``stability_repeat`` does (not re-normalised, names carried over; all-zero rows / columns
+        dropped first, ``_trim_samples``) -- on the device, device SVD init, loop, finalise.
+        ``return_init`` / ``return_data`` add the initial (F, S, G, lambda, mu) per view and the device's copy of the
+        data actually factorised (fp32 precision) to the result: what a reference run needs to start from the same place."""
         from . import naming
         from .engine import Engine
         n_v = len(self.data_shapes)
+        if samples is not None:
+            samples = self._trim_samples(samples)
+            if samples is None:
+                return {"stability_performed": False, "tag": tag}          # R/stability_analysis.r:223-226
         shapes = self.data_shapes if samples is None else [(len(samples[0][v]), len(samples[1][v])) for v in range(n_v)]
         rn, cn = self.rn, self.cn
         if samples is not None:
@@ -224,7 +265,13 @@ class DeviceData:
             shuffled = shuffle_seed is not None
             for v in range(n_v):
                 if shuffled:
-                    eng.shuffle_view_from(v, self.base, v, seed=shuffle_seed * 1000003 + v)
+                    for attempt in range(64):                              # R/obtain_bicl.r:14-18: redraw on an empty row / column
+                        eng.shuffle_view_from(v, self.base, v, seed=(shuffle_seed + 7919 * attempt) * 1000003 + v)
+                        er, ec = eng.empty_lines(v)
+                        if not (er.any() or ec.any()):
+                            break
+                    else:
+                        raise RuntimeError("shuffle_view: every draw left an all-zero row or column")
                 elif samples is not None:
                     eng.subsample_view_from(v, self.base, v, samples[0][v], samples[1][v])
                 else:
@@ -240,15 +287,23 @@ class DeviceData:
                         if v != w:
                             eng.set_shared_rows(v, w, *naming.index_pairs(rn[v], rn[w], rs[v].get(w)))
                             eng.set_shared_cols(v, w, *naming.index_pairs(cn[v], cn[w], cs[v].get(w)))
+            init_state = [eng.get_factors(v) for v in range(n_v)] if return_init else None
+            data_used = [eng.get_view(v) for v in range(n_v)] if return_data else None
             errs = eng.run(n_iters=n_iters, tol=1.0e-6, max_iters=max_iters)
             fin = [eng.finalise(v) for v in range(n_v)]
         finally:
             eng.close()
         error = float(np.mean(errs[-10:])) if n_iters is None else float(errs[-1])           # R/main.r:126-130
-        return {"output_f": [f[0] for f in fin], "output_s": [f[1] for f in fin], "output_g": [f[2] for f in fin],
-                "row_clusters": [f[3] for f in fin], "col_clusters": [f[4] for f in fin],
-                "Error": error, "All_Error": errs, "tag": tag,
-                "extras": {} if samples is None else {"row_samples": samples[0], "col_samples": samples[1]}}
+        res = {"output_f": [f[0] for f in fin], "output_s": [f[1] for f in fin], "output_g": [f[2] for f in fin],
+               "row_clusters": [f[3] for f in fin], "col_clusters": [f[4] for f in fin],
+               "Error": error, "All_Error": errs, "tag": tag,
+               "extras": {} if samples is None else {"row_samples": samples[0], "col_samples": samples[1]},
+               "row_names": rn, "col_names": cn}
+        if return_init:
+            res["init"] = init_state
+        if return_data:
+            res["data"] = data_used
+        return res
 
 
 def k_sweep_on_device(dev: DeviceData, k_min: int = 3, k_max: int = 8, n_iters=None, seed: int = 0, group=None) -> List[dict]:
@@ -268,8 +323,10 @@ def shuffles_on_device(dev: DeviceData, n_clusts: int, num_repeats: int = 5, n_i
 def stability_on_device(dev: DeviceData, k: int, n_stability: int = 5, sample_rate: float = 0.9, n_iters=None, seed: int = 0,
                         group=None) -> List[dict]:
     """The factorisations of ``stability_check`` (``R/stability_analysis.r:305-323``): the draws follow
-    ``subsample_views`` (shared draws for equal extents; the empty-row / empty-column trimming is vacuous on the
-    strictly positive pre-processed data kept on the device), the sub-samples are gathered on the device."""
+    ``subsample_views`` (shared draws for equal extents), the sub-samples are gathered on the device; all-zero rows /
+    columns of a sub-sample -- the pre-processed data are non-negative, not positive: ``make_non_neg`` leaves a zero
+    at every shifted column's minimum and sparse inputs stay sparse -- are dropped as the reference does
+    (``DeviceData._trim_samples``); a repeat whose sampling fails returns ``stability_performed = False``."""
     rng = np.random.default_rng(seed)
     draws = []
     for _ in range(n_stability):

@@ -45,6 +45,8 @@ struct SharedMap {
 struct ViewState {
   int n = 0, m = 0, k = 0, KP = 16, NT = 1;
   bool owned = true, has_x = false, has_factors = false;
+  int empty_rows = 0, empty_cols = 0;          // all-zero rows / columns of the latest device-drawn data (shuffle, sub-sample)
+  std::vector<unsigned char> empty_mask;     // [n + m], 1 = the row / column sums to zero
   int n_pad = 0, m_pad = 0;
   size_t ldx = 0, ldxt = 0;      // TILE strides of X32 / Xt32 (floats): tile t (64 columns) is a contiguous [rows_pad][64] block
   size_t x32_floats = 0, xt32_floats = 0;
@@ -102,6 +104,7 @@ struct resnmtf_handle {
   // ladder of captured sweep graphs: check_every sweeps plus every smaller power of two, so that any run length
   // is a handful of graph launches (R/main.r:83-108 is the loop being replayed)
   std::vector<std::pair<int, hipGraphExec_t>> ladder;      // (sweeps, executable), descending
+  std::vector<std::pair<int, hipGraphExec_t>> exact;       // short runs (< 3 batches) repeated with the same length: one graph each
   double graph_tol = -2.0;
   bool resume_ok = false;             // the device state is exactly what the run prologue would produce: skip it
   bool ctl_clean = false;             // ... and the loop control needs no reset either (fixed sweeps after fixed sweeps):
@@ -464,6 +467,9 @@ void destroy_graphs(resnmtf_handle* h) {
   for (auto& rung : h->ladder)
     if (rung.second) (void)hipGraphExecDestroy(rung.second);
   h->ladder.clear();
+  for (auto& g : h->exact)
+    if (g.second) (void)hipGraphExecDestroy(g.second);
+  h->exact.clear();
   h->graph_tol = -2.0;
 }
 
@@ -480,7 +486,9 @@ int capture_graph(resnmtf_handle* h, int sweeps, double tol, hipGraphExec_t* out
 }
 // the whole ladder at once (a few hundred kernel nodes): a later run of any length never captures inside a timed region
 int capture_ladder(resnmtf_handle* h, int batch, double tol) {
-  destroy_graphs(h);
+  for (auto& rung : h->ladder)
+    if (rung.second) (void)hipGraphExecDestroy(rung.second);
+  h->ladder.clear();
   std::vector<int> rungs{batch};
   int p2 = 1;
   while (p2 * 2 < batch) p2 *= 2;
@@ -491,7 +499,6 @@ int capture_ladder(resnmtf_handle* h, int batch, double tol) {
     if (int rc = capture_graph(h, sweeps, tol, &ex)) { destroy_graphs(h); return rc; }
     h->ladder.emplace_back(sweeps, ex);
   }
-  h->graph_tol = tol;
   return RESNMTF_OK;
 }
 
@@ -1018,6 +1025,20 @@ int upload_view(resnmtf_handle* h, int v, const double* x, bool raw, int* was_ne
                          shuffle_src->ldx, vs.n, vs.m, shuffle_src->seed, staging);
     e = hipGetLastError();
   }
+  unsigned char* line_mask = nullptr;      // device-drawn data: which rows / columns came out all zero
+  std::vector<int> line_counts(2, 0);
+  vs.empty_rows = vs.empty_cols = 0; vs.empty_mask.clear();
+  if (e == hipSuccess && !x) {
+    e = hipMalloc(reinterpret_cast<void**>(&line_mask), (size_t)vs.n + vs.m + 2 * sizeof(int) + 8);
+    if (e == hipSuccess) {
+      int* counts = reinterpret_cast<int*>(line_mask + (((size_t)vs.n + vs.m + 7) / 8) * 8);
+      e = hipMemsetAsync(counts, 0, 2 * sizeof(int), h->stream);
+      hipLaunchKernelGGL(empty_lines_kernel, dim3(ceil_div(vs.n + vs.m, 256)), dim3(256), 0, h->stream, staging, vs.n, vs.m, line_mask, counts);
+      vs.empty_mask.resize((size_t)vs.n + vs.m);
+      if (e == hipSuccess) e = hipMemcpyAsync(vs.empty_mask.data(), line_mask, (size_t)vs.n + vs.m, hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(line_counts.data(), counts, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream);
+    }
+  }
   if (e == hipSuccess) e = hipMemsetAsync(vs.X32, 0, vs.x32_floats * sizeof(float), h->stream);
   if (e == hipSuccess) e = hipMemsetAsync(vs.Xt32, 0, vs.xt32_floats * sizeof(float), h->stream);
   if (e == hipSuccess && raw) e = hipMemsetAsync(neg, 0, sizeof(double), h->stream);
@@ -1033,7 +1054,9 @@ int upload_view(resnmtf_handle* h, int v, const double* x, bool raw, int* was_ne
   (void)hipFree(staging);
   (void)hipFree(partial);
   (void)hipFree(colstat);
+  (void)hipFree(line_mask);
   if (e != hipSuccess) return h->fail_hip("set_view", e);
+  vs.empty_rows = line_counts[0]; vs.empty_cols = line_counts[1];
   if (was_negative) *was_negative = neg_host;
   vs.has_x = true;
   if (vs.half_capable) return build_half_images(h, vs);
@@ -1108,6 +1131,18 @@ int resnmtf_subsample_view(resnmtf_handle* dst, int v, resnmtf_handle* src, int 
   const int rc = upload_view(dst, v, nullptr, false, nullptr, &sh);      // sub-samples are NOT re-normalised (Appendix B11)
   (void)hipFree(idx);
   return rc;
+}
+
+int resnmtf_view_empty_lines(resnmtf_handle* h, int v, int* n_empty_rows, int* n_empty_cols, unsigned char* row_mask,
+                             unsigned char* col_mask) {
+  if (int rc = check_view(h, v)) return rc;
+  const ViewState& vs = h->views[v];
+  if (n_empty_rows) *n_empty_rows = vs.empty_rows;
+  if (n_empty_cols) *n_empty_cols = vs.empty_cols;
+  const bool have = vs.empty_mask.size() == (size_t)vs.n + vs.m;
+  if (row_mask) for (int r = 0; r < vs.n; ++r) row_mask[r] = have ? vs.empty_mask[(size_t)r] : 0;
+  if (col_mask) for (int c = 0; c < vs.m; ++c) col_mask[c] = have ? vs.empty_mask[(size_t)vs.n + c] : 0;
+  return RESNMTF_OK;
 }
 
 int resnmtf_get_view(resnmtf_handle* h, int v, double* x) {
@@ -1755,9 +1790,33 @@ int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, doubl
   h->resume_ok = false;
   const bool eager = !h->opt.use_graph || h->opt.time_kernels;
   const int batch = std::max(1, h->opt.check_every);
-  if (!eager && (h->graph_tol != tol_arg || h->ladder.empty() || h->ladder.front().first != batch))
-    if (int rc = capture_ladder(h, batch, tol_arg)) return rc;
+  if (!eager && h->graph_tol != tol_arg) { destroy_graphs(h); h->graph_tol = tol_arg; }     // graphs are captured per stop test
   int enq = 0;
+  if (!eager && total > 1) {
+    // the first sweep goes out as plain launches: its first kernel starts within a few microseconds, where a graph launch
+    // costs the host ~20 us before the GPU sees anything (tools/time_run_overhead.py); the graph launches that follow
+    // are enqueued while that sweep runs.  (Same kernels, same arguments: bit for bit the graph's.)
+    enqueue_sweep(h, tol_arg);
+    enq = 1;
+  }
+  // fixed-iteration runs shorter than three batches: ONE graph of exactly the sweeps left (captured at the first run of
+  // that length, kept for the next ones -- a driver that times `run(20)` after a warm-up call of the same length pays
+  // one graph launch, hidden behind the eager first sweep, and no graph-to-graph gaps)
+  if (!eager && tol_arg < 0.0 && total - enq > 0 && total - enq < 3 * batch) {
+    const int rest = total - enq;
+    hipGraphExec_t ex = nullptr;
+    for (const auto& g : h->exact)
+      if (g.first == rest) ex = g.second;
+    if (!ex) {
+      if (h->exact.size() >= 4) { (void)hipGraphExecDestroy(h->exact.front().second); h->exact.erase(h->exact.begin()); }
+      if (int rc = capture_graph(h, rest, tol_arg, &ex)) return rc;
+      h->exact.emplace_back(rest, ex);
+    }
+    HIP_TRY(h, hipGraphLaunch(ex, h->stream));
+    enq = total;
+  }
+  if (!eager && enq < total && (h->ladder.empty() || h->ladder.front().first != batch))
+    if (int rc = capture_ladder(h, batch, tol_arg)) return rc;
   while (enq < total) {
     const int todo = std::min(batch, total - enq);
     if (eager) {
@@ -1767,12 +1826,13 @@ int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, doubl
           if (int rc = flush_timing(h)) return rc;
       }
     } else {
-      int left = todo;                       // a full batch is one launch; a remainder a few (binary ladder)
+      // a full batch is one launch; a remainder a few (binary ladder), SMALLEST rung first: the host cost of a graph launch
+      // grows with its nodes, and everything after the first launch is enqueued while the GPU already works
+      int left = todo;
+      std::vector<hipGraphExec_t> seq;
       for (const auto& rung : h->ladder)
-        while (left >= rung.first) {
-          HIP_TRY(h, hipGraphLaunch(rung.second, h->stream));
-          left -= rung.first;
-        }
+        while (left >= rung.first) { seq.push_back(rung.second); left -= rung.first; }
+      for (auto it = seq.rbegin(); it != seq.rend(); ++it) HIP_TRY(h, hipGraphLaunch(*it, h->stream));
     }
     enq += todo;
     if (tol_arg >= 0.0) {     // convergence mode (R/main.r:50-81): look at the (mirrored) device flag between batches

@@ -134,6 +134,16 @@ class Engine:
             raise ValueError("index counts must equal the view's shape")
         self._check(self._lib.resnmtf_subsample_view(self._h, v, other._h, v_src, _ip(rows), _ip(cols)))
 
+    def empty_lines(self, v: int):
+        """(row_mask, col_mask) of view ``v``'s latest device-drawn data (shuffle / sub-sample): True where a row / column
+        sums to exactly zero -- the condition of the reference's redraw (``R/obtain_bicl.r:14-18``) and of its trimming
+        of sub-samples (``R/stability_analysis.r:165-190``)."""
+        nr, nc = C.c_int(0), C.c_int(0)
+        rm = np.zeros(self.n_rows[v], dtype=np.uint8); cm = np.zeros(self.n_cols[v], dtype=np.uint8)
+        self._check(self._lib.resnmtf_view_empty_lines(self._h, v, C.byref(nr), C.byref(nc),
+                                                       rm.ctypes.data_as(C.POINTER(C.c_ubyte)), cm.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        return rm.astype(bool), cm.astype(bool)
+
     def get_view(self, v: int) -> np.ndarray:
         """The device copy of the view's data (fp32 precision) as an fp64 matrix."""
         x = np.zeros((self.n_rows[v], self.n_cols[v]), order="F")
@@ -185,10 +195,14 @@ class Engine:
         if n_iters is not None and n_iters <= 0:
             raise ValueError("n_iters must be positive (None = run to convergence)")
         cap = int(n_iters) if n_iters else int(max_iters)
-        errs = np.zeros(cap, dtype=np.float64)
-        done = C.c_int(0)
-        self._check(self._lib.resnmtf_run(self._h, int(n_iters or 0), float(tol), int(max_iters), _dp(errs), cap,
-                                          C.byref(done)))
+        buf = self.__dict__.get("_err_buf")
+        if buf is None or buf[0].size < cap:            # (kept across calls: a short run is a few hundred microseconds)
+            arr = np.empty(max(cap, 1024), dtype=np.float64)
+            buf = self._err_buf = (arr, arr.ctypes.data_as(C.POINTER(C.c_double)), C.c_int(0))
+        errs, ptr, done = buf
+        rc = self._lib.resnmtf_run(self._h, int(n_iters or 0), float(tol), int(max_iters), ptr, cap, C.byref(done))
+        if rc != _lib.OK:
+            self._check(rc)
         return errs[:done.value].copy()
 
     def reserve_sweeps(self, sweeps: int):

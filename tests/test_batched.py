@@ -167,3 +167,105 @@ def test_device_subsample_is_the_index_gather():
     with pytest.raises(ResnmtfError, match="out of range"):
         e.subsample_view_from(0, base, 0, rows + 60, cols)
     e.close(); base.close()
+
+
+def _oracle_from(res, data, phi, xi, psi, row_names, col_names, n_iters):
+    """The oracle on the data a batched job factorised, from the initial state the device built (``res["init"]``)."""
+    from oracle import resnmtf_oracle as O
+    init = res["init"]
+    return O.res_nmtf_inner(data, [s[0] for s in init], [s[1] for s in init], [s[2] for s in init], phi, xi, psi,
+                            row_names=row_names, col_names=col_names, init_lam=[s[3] for s in init],
+                            init_mu=[s[4] for s in init], n_iters=n_iters)
+
+
+def _close(res, ref, n_v, tol=2e-5):
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import rel_fro
+    np.testing.assert_allclose(res["All_Error"], ref["All_Error"], atol=2e-5)
+    for v in range(n_v):
+        assert rel_fro(res["output_f"][v], ref["output_f"][v]) < tol, f"F view {v}"
+        assert rel_fro(res["output_g"][v], ref["output_g"][v]) < tol, f"G view {v}"
+        assert rel_fro(res["output_s"][v], ref["output_s"][v]) < 1e-4, f"S view {v}"
+        assert np.array_equal(res["row_clusters"][v], ref["row_clusters"][v])
+        assert np.array_equal(res["col_clusters"][v], ref["col_clusters"][v])
+
+
+@pytest.mark.gpu
+def test_one_batched_job_of_each_kind_matches_the_oracle():
+    """the repeated factorisations around the loop.  One job of each kind -- candidate k of the k sweep
+    (R/main.r:279-290), a shuffled copy (R/obtain_bicl.r:11-42), a stability sub-sample (R/stability_analysis.r:215-278)
+    -- run through the batched driver, host-built data and device-resident data, and compared with the oracle run on
+    the SAME data (host-shuffled / host-sub-sampled, or the device's copy read back) from the SAME initial factors
+    (the device's SVD initialisation, returned by the job): All_Error, F, S, G and identical cluster matrices."""
+    from oracle import resnmtf_oracle as O
+    from resnmtf_amd import naming
+    rng = np.random.default_rng(9)
+    rcm = np.kron(np.eye(3), np.ones((40, 1))); ccm = np.kron(np.eye(3), np.ones((30, 1)))
+    x = [rcm @ (10.0 * np.eye(3)) @ ccm.T + 0.1 * np.abs(rng.normal(size=(120, 90))),
+         rcm @ (8.0 * np.eye(3)) @ ccm.T + 0.1 * np.abs(rng.normal(size=(120, 90)))]
+    phi = np.zeros((2, 2)); phi[0, 1] = 1.5                        # raw restriction matrix: apply_resnmtf symmetrises it
+    iters = 40
+    z = np.zeros((2, 2))
+    # ---- host-built jobs (batched.run_job): data as the job holds it, pre-processed as apply_resnmtf does
+    jobs = [batched.k_sweep_jobs(x, 4, 4, phi=phi, n_iters=iters)[0],
+            batched.shuffled_jobs(x, 3, num_repeats=1, seed=3, n_iters=iters)[0],
+            batched.stability_jobs(x, 3, n_stability=1, phi=phi, n_iters=iters, seed=5)[0]]
+    for job in jobs:
+        res = batched.run_job(job, return_init=True)
+        data = naming.check_data([np.asarray(d, dtype=np.float64) for d in job.data])
+        rn, cn = naming.give_names(data, job.phi, job.psi, job.row_names, job.col_names)
+        ref = _oracle_from(res, data, naming.init_rest_mats(job.phi, 2), z, naming.init_rest_mats(job.psi, 2), rn, cn, iters)
+        _close(res, ref, 2)
+    # ---- the same kinds with the data resident on the device: the oracle gets the device's copy read back
+    dev = batched.DeviceData(x, phi=phi)
+    rows = [rng.choice(120, 100, replace=False)] * 2; cols = [rng.choice(90, 80, replace=False)] * 2
+    for kw, coupled in ((dict(k=4), True), (dict(k=3, shuffle_seed=17), False), (dict(k=3, samples=(rows, cols)), True)):
+        res = dev.factorise(n_iters=iters, seed=2, return_init=True, return_data=True, **kw)
+        p = dev.phi if coupled else z
+        rn, cn = (res["row_names"], res["col_names"]) if coupled else naming.give_names(res["data"], None, None)
+        ref = _oracle_from(res, res["data"], p, z, z, rn, cn, iters)
+        _close(res, ref, 2)
+        if "shuffle_seed" in kw:                                   # column-normalised shuffled data (R/obtain_bicl.r:35 -> utils.r:422)
+            np.testing.assert_allclose(res["data"][0].sum(0), 1.0, rtol=1e-5)
+    dev.close()
+    assert O is not None
+
+
+@pytest.mark.gpu
+def test_device_draws_with_empty_rows_and_columns_are_redrawn_or_trimmed():
+    """R/obtain_bicl.r:14-18 redraws a shuffle that has an all-zero row or column; R/stability_analysis.r:165-190,
+    :233-240 drop all-zero rows / columns of a sub-sample.  Sparse data: 97 % zeros."""
+    from resnmtf_amd.engine import Engine
+    rng = np.random.default_rng(2)
+    x = np.abs(rng.normal(size=(60, 40))) * (rng.random((60, 40)) < 0.03)
+    x[:, 0] = 1.0; x[0, :] = 1.0                                    # (every column / row of X itself is non-empty)
+    x[5, 1:] = 0.0; x[1:, 7] = 0.0                                  # ... but row 5 / column 7 only through row 0 / column 0
+    base = Engine([60], [40], [2]); base.set_view(0, x / x.sum(0)[None, :])
+    e = Engine([59], [39], [2])
+    rows = np.arange(1, 60); cols = np.arange(1, 40)               # sub-sample without row 0 / column 0
+    e.subsample_view_from(0, base, 0, rows, cols)
+    er, ec = e.empty_lines(0)
+    sub = (x / x.sum(0)[None, :])[np.ix_(rows, cols)]
+    assert np.array_equal(er, sub.sum(1) == 0) and np.array_equal(ec, sub.sum(0) == 0)
+    assert er[4] and ec[6]                                          # row 5 / column 7 of X
+    e.close()
+    dev = batched.DeviceData([x])
+    trimmed = dev._trim_samples(([rows], [cols]))
+    assert trimmed is not None
+    tr, tc = trimmed
+    final = (x / x.sum(0)[None, :])[np.ix_(tr[0], tc[0])]
+    assert (final.sum(0) != 0).all() and (final.sum(1) != 0).all() and 5 not in tr[0] and 7 not in tc[0]
+    res = dev.factorise(2, n_iters=10, samples=([rows], [cols]))
+    assert res["output_f"][0].shape[0] == len(tr[0]) and np.isfinite(res["All_Error"]).all()
+    # shuffles: every accepted draw has no empty row or column (the sparse matrix makes most raw draws fail)
+    s = Engine([60], [40], [2])
+    accepted = 0
+    for seed in range(40):
+        s.shuffle_view_from(0, dev.base, 0, seed=seed, normalise=False)
+        er, ec = s.empty_lines(0)
+        m = s.get_view(0)
+        assert np.array_equal(er, m.sum(1) == 0) and np.array_equal(ec, m.sum(0) == 0)
+        accepted += int(not (er.any() or ec.any()))
+    assert accepted < 40                                           # the redraw loop has work to do on such data
+    s.close(); dev.close(); base.close()
