@@ -83,10 +83,14 @@ def pass_roofline(make_engine, steps: int, warmup: int) -> dict:
                 "xg_avg_us": round(t["xg_ms_total"] / max(t["xg_launches"], 1) * 1e3, 3),
                 "xtf_avg_us": round(t["xtf_ms_total"] / max(t["xtf_launches"], 1) * 1e3, 3),
                 "mfma_tflops": round((t["xg_flops"] + t["xtf_flops"]) / 2 / (pass_ms * 1e-3) / 1e12, 2)}
+    # `traffic` cannot be measured inside this run (PMC passes need their own rocprofv3 runs): it is the figure of the
+    # committed PMC session, labelled as such (profiles/README.md; tools/profile_round.sh regenerates it)
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(traffic_file):          # HBM bytes per launch from the PMC passes (profiles/README.md)
+    if os.path.exists(traffic_file):
         try:
-            roofline["traffic"] = json.load(open(traffic_file)).get("atb_pass_kernel_bytes_per_launch")
+            t = json.load(open(traffic_file))
+            roofline["traffic"] = t.get("atb_pass_kernel_bytes_per_launch")
+            roofline["traffic_source"] = "static: profiles/traffic.json (" + str(t.get("source", "PMC session")) + ")"
         except Exception:
             pass
     return roofline

@@ -46,7 +46,12 @@ enum { RESNMTF_FACTOR_F = 0, RESNMTF_FACTOR_G = 1, RESNMTF_FACTOR_S = 2,
        RESNMTF_FACTOR_FBLOCK = 3, /* replicate_f: the F update's inputs [U (X.G, one f32 slab) | Ma_F | Md_F | lambda], contiguous */
        RESNMTF_FACTOR_FBLOCK_ALL = 4 /* replicate_f: the blocks of ALL views, contiguous in view order (v is ignored beyond its
                                         range check); equal-shaped views have equal block sizes, so one in-place all-gather
-                                        over ranks that own one view each refreshes every block */ };
+                                        over ranks that own one view each refreshes every block */,
+       RESNMTF_FACTOR_GBLOCK = 5, /* replicate_gs: the G update's inputs [T (Xt.F, one f32 slab) | Ma_G | Md_G | mu] of view v */
+       RESNMTF_FACTOR_GBLOCK_ALL = 6, /* ... of all views, contiguous in view order */
+       RESNMTF_FACTOR_SBLOCK = 7, /* replicate_gs: the S update's inputs of view v (fp64: old S | F^T X G | (F^T F S)(G^T G) |
+                                     G^T G | F^T F | colSums(G) | colSums(F) | ||X||^2) */
+       RESNMTF_FACTOR_SBLOCK_ALL = 8 /* ... of all views, contiguous in view order (equal k: equal blocks) */ };
 
 /* phases of one view's update inside a sweep (R/update_steps.r:282-314) */
 enum {
@@ -62,7 +67,14 @@ enum {
                              the same order and at most four of them are owned; one launch per view otherwise.  resnmtf_run
                              hoists the F updates of a sweep the same way when that launch applies */,
   RESNMTF_PHASE_LOCAL_SWEEP = 4 /* RESNMTF_PHASE_F_ALL followed by RESNMTF_PHASE_G of every owned view: everything a rank
-                             does between two exchanges of the F blocks when no G or S crosses ranks, in one call */
+                             does between two exchanges of the F blocks when no G or S crosses ranks, in one call */,
+  /* replicate_gs (view argument = any owned view for the _ALL phases):
+   *   sweep = F_ALL, XTF(own), [all-gather G blocks], G_ALL, XG(own), [all-gather S blocks], S_ALL, [all-gather F blocks] */
+  RESNMTF_PHASE_XTF = 5   /* Xt.F pass of owned view v + its k x k job (F'^T F', Ma_G, Md_G) + fold of T into the G block */,
+  RESNMTF_PHASE_G_ALL = 6 /* update_g of EVERY view, in view order (R/update_steps.r:180-207, :295-303) from the G blocks */,
+  RESNMTF_PHASE_XG = 7    /* X.G' pass of owned view v + first half of its k x k job (inputs of the S rule -> S block) +
+                             fold of U into the F block */,
+  RESNMTF_PHASE_S_ALL = 8 /* update_s, update_lm, error and the F coefficients of EVERY view (s_chain_kernel) */
 };
 
 typedef struct resnmtf_handle resnmtf_handle;
@@ -71,28 +83,33 @@ typedef struct resnmtf_options {
   int struct_size;        /* = sizeof(resnmtf_options); set by resnmtf_default_options */
   int device_id;          /* HIP device ordinal; one process per GPU (default 0) */
   void* stream;           /* hipStream_t to enqueue on; NULL = library-owned stream */
-  int use_graph;          /* 1 (default): capture one sweep into a hipGraph and replay it */
+  int use_graph;          /* 1 (default): the sweeps of a run are replayed from captured hipGraphs (one graph of the exact
+                             length for short fixed runs, else batches of check_every and a power-of-two ladder for the rest) */
   int check_every;        /* convergence mode: sweeps enqueued per host-side check (default 32; launches after the stop
                              test fired return at once) */
-  int target_workgroups;  /* waves per streaming pass (sizes splits x waves-per-workgroup); 0 = default 4096 */
+  int target_workgroups;  /* workgroup slots a streaming pass is sized for; 0 = default: CUs x resident workgroups per CU
+                             (two at k <= 16, one above) */
   int time_kernels;       /* 1: bracket every streaming-pass launch with HIP events (eager mode) */
   /* tuning overrides of the streaming-pass geometry (0 = automatic), see DESIGN.md section 5 */
   int pass_waves;         /* waves per workgroup: 4, 8 or 16 (0 = auto) */
   int pass_splits_xg;     /* row splits of the X.G pass */
   int pass_splits_xtf;    /* row splits of the Xt.F pass */
   int pass_lds_pad_kb;    /* extra dynamic LDS per workgroup (caps workgroups per CU) */
-  int update_blocks;      /* workgroups per factor-update launch (default 256) */
+  int update_blocks;      /* workgroups per factor-update launch; 0 = default: ~160 (512 above 256 MB of X) in hand-off
+                             mode A, one row group per workgroup up to 1024 in mode B */
   int no_pitch_pad;       /* 1: do not pad row pitches that are multiples of 4 KiB (A/B testing) */
   int kk_mode;            /* where the k x k products come from: 0 auto, 1 = A (fp64 partials of the update
                              kernels, job in workgroup 0 of the pass launch), 2 = B (MFMA aux tiles, job in
                              the last-arriving aux workgroup); DESIGN.md section 4 */
   int bf16_split;         /* MFMA form of the two big contractions for k > 16 (k <= 16 always uses the f32 MFMA):
-                             0 (default) both operands split in registers into THREE bf16 pieces, six bf16 MFMAs
-                               per product group -- dropped terms <= 2^-24: f32-grade, parity as the f32 MFMA,
-                               c5-sized view +14 % (the f32 MFMA pipe limits k > 32);
-                             1 TWO pieces, three MFMAs (16 bits of mantissa): c5 +45 %, F / G within
-                               1e-5 ... 6e-5 of the fp64 reference instead of 1e-6 ... 8e-6 (bar 1e-4);
-                             2 plain v_mfma_f32_16x16x4_f32 */
+                             0 (default) both operands as THREE bf16 pieces (each rounded to nearest even; X split in
+                               registers, the factor's pieces written K-packed by the update kernels), six
+                               v_mfma_f32_16x16x32_bf16 per product group in WIDE workgroups (8 or 4 tiles share one
+                               LDS copy of the factor block) -- dropped terms <= 2^-26: f32-grade (F / G 2e-7 ... 7e-6
+                               from the fp64 reference, the f32 MFMA 1e-7 ... 6e-6);
+                             1 accepted as an alias of 0 (the former two-piece form is retired: the K = 32 three-piece
+                               form is faster than it was);
+                             2 plain v_mfma_f32_16x16x4_f32, one tile per workgroup */
   int replicate_f;        /* view-sharded use (phase API): 1 = every rank keeps, for EVERY view, the inputs of its F
                              update (X.G folded into one f32 slab, the two k x k coefficient matrices, lambda) in one
                              contiguous exchange block (RESNMTF_FACTOR_FBLOCK) and may run RESNMTF_PHASE_F on views it does
@@ -110,6 +127,14 @@ typedef struct resnmtf_options {
                              pieces, 22 bits), f32 accumulate.  F / G then sit within ~2e-5 of the fp64 reference instead of
                              ~1e-6 (bar 1e-4); DESIGN.md section 3 */
   int half_unroll;        /* 2-byte passes: wave-steps (16 rows each) per trip: 2, 3, 4 or 6 (0 = default: 4 for fp16, 2 for integers) */
+  int replicate_gs;       /* view-sharded use, with replicate_f: 1 = the G and S chains are replicated too.  Every rank keeps,
+                             for EVERY view, the inputs of its G update (Xt.F folded into one f32 slab, Ma_G, Md_G, mu:
+                             RESNMTF_FACTOR_GBLOCK) and of its S update (old S, F^T X G, (F^T F S)(G^T G), the two Gram
+                             matrices, column sums, ||X||^2: RESNMTF_FACTOR_SBLOCK), runs RESNMTF_PHASE_G_ALL /
+                             RESNMTF_PHASE_S_ALL for all views itself and only streams its own X (RESNMTF_PHASE_XTF /
+                             RESNMTF_PHASE_XG): three all-gathers per sweep (T blocks, S blocks, U blocks) instead of
+                             2 V ordered broadcasts, and the two streaming passes of all ranks run at the same time
+                             (psi / xi coupling; R/update_steps.r:195-204, :231-237).  Needs equal k in all views. */
 } resnmtf_options;
 
 typedef struct resnmtf_pass_timing {

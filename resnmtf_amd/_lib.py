@@ -15,7 +15,9 @@ LIB_PATH = os.path.join(_HERE, "libresnmtf_hip.so")
 OK = 0
 ERR_NAMES = {1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "ALLOC", 5: "STATE"}
 FACTOR_F, FACTOR_G, FACTOR_S, FACTOR_FBLOCK, FACTOR_FBLOCK_ALL = 0, 1, 2, 3, 4
+FACTOR_GBLOCK, FACTOR_GBLOCK_ALL, FACTOR_SBLOCK, FACTOR_SBLOCK_ALL = 5, 6, 7, 8
 PHASE_F, PHASE_G, PHASE_S, PHASE_F_ALL, PHASE_LOCAL_SWEEP = 0, 1, 2, 3, 4
+PHASE_XTF, PHASE_G_ALL, PHASE_XG, PHASE_S_ALL = 5, 6, 7, 8
 MAX_K = 64
 
 
@@ -32,7 +34,7 @@ class Options(C.Structure):
         ("time_kernels", C.c_int), ("pass_waves", C.c_int), ("pass_splits_xg", C.c_int),
         ("pass_splits_xtf", C.c_int), ("pass_lds_pad_kb", C.c_int), ("update_blocks", C.c_int),
         ("no_pitch_pad", C.c_int), ("kk_mode", C.c_int), ("bf16_split", C.c_int), ("replicate_f", C.c_int),
-        ("no_f_chain", C.c_int), ("x_half", C.c_int), ("half_unroll", C.c_int),
+        ("no_f_chain", C.c_int), ("x_half", C.c_int), ("half_unroll", C.c_int), ("replicate_gs", C.c_int),
     ]
 
 

@@ -72,6 +72,10 @@ struct ViewState {
   size_t fblk_bytes = 0;             // slice of the handle's arena; Usum = the X.G split slabs folded into one f32 slab
   float* Usum = nullptr;
   bool f_replica = false;            // non-owned view whose F update runs here too (replicate_f)
+  void* gblk = nullptr; size_t gblk_bytes = 0;   // replicate_gs: [Tsum | Ma_G | Md_G | mu] (the G update's inputs), arena slice
+  float* Tsum = nullptr;             //   Tsum = the Xt.F split slabs folded into one f32 slab
+  bool g_replica = false;            // non-owned view whose G update runs here too (replicate_gs)
+  double* sblk = nullptr;            // replicate_gs: the S update's inputs (sblock_layout), arena slice
   bool pp_xg = false, pp_xtf = false; // k <= 16, streamed geometry: ping-pong prefetch form of the pass (UNROLL 4)
   int kk_mode = 0;                   // 0 = A: Gram partials from the update kernels, k x k job = workgroup 0
                                      // 1 = B: Gram/cross/colsum on MFMA aux tiles, k x k job = last-arriving aux workgroup
@@ -120,6 +124,8 @@ struct resnmtf_handle {
   int chain_blocks = 0;
   void* fblk_arena = nullptr;         // replicate_f: the F exchange blocks of all views, in view order
   size_t fblk_arena_bytes = 0;
+  void* gblk_arena = nullptr; size_t gblk_arena_bytes = 0;     // replicate_gs: the G / S exchange blocks of all views
+  double* sblk_arena = nullptr; size_t sblk_stride = 0;        //   (S blocks: sblk_stride doubles each)
   // pass timing (eager mode)
   std::vector<hipEvent_t> ev;         // pairs
   std::vector<int> ev_kind;           // 0 = xg, 1 = xtf per pair
@@ -154,6 +160,8 @@ hipError_t dev_alloc_zero(T** p, size_t count) {
 
 void free_view(ViewState& v) {
   if (v.fblk) { v.fblk = nullptr; v.Usum = nullptr; v.Ma_F = nullptr; v.Md_F = nullptr; v.lambda = nullptr; }   // arena slices
+  if (v.gblk) { v.gblk = nullptr; v.Tsum = nullptr; v.Ma_G = nullptr; v.Md_G = nullptr; v.mu = nullptr; }
+  v.sblk = nullptr;
   void* ptrs[] = {v.Fk, v.Gk, v.X16, v.Xt16, v.X32, v.Xt32, v.xnorm2, v.F, v.G, v.S, v.lambda, v.mu, v.F32, v.G32, v.T32, v.Pxg, v.Pxtf,
                   v.Paux_xg, v.Paux_xtf, v.cnt_xg, v.cnt_xtf, v.partF, v.partG, v.FtF, v.FtFS, v.cF, v.Ma_F, v.Md_F, v.Ma_G, v.Md_G};
   for (void* p : ptrs)
@@ -245,6 +253,10 @@ hipError_t set_all_attrs() {
   TRY_ATTR(set_smem_attrs<48>()); TRY_ATTR(set_smem_attrs<64>());
   TRY_ATTR((set_pass_attr<1, 4, 8>())); TRY_ATTR((set_pass_attr<1, 8, 8>())); TRY_ATTR((set_pass_attr<1, 8, 4>())); TRY_ATTR((set_pass_attr<1, 16, 8>()));
   TRY_ATTR((set_pass_attr<2, 8, 4>())); TRY_ATTR((set_pass_attr<3, 8, 4>())); TRY_ATTR((set_pass_attr<4, 8, 4>()));
+  TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&s_chain_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+  TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&s_chain_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+  TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&s_chain_kernel<48>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+  TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&s_chain_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
 #define CHAIN_ATTR(NVB, PFV) TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&f_chain_kernel<NVB, PFV>), \
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)f_chain_smem_bytes<NVB>()))
   CHAIN_ATTR(2, 1); CHAIN_ATTR(4, 1); CHAIN_ATTR(8, 1); CHAIN_ATTR(2, 4); CHAIN_ATTR(4, 4); CHAIN_ATTR(8, 4);
@@ -435,6 +447,43 @@ void launch_fold(resnmtf_handle* h, const ViewState& v) {
   if (!v.Usum) return;
   const int quads = v.n_pad * v.KP / 4;
   hipLaunchKernelGGL(slab_fold_kernel, dim3(ceil_div(quads, 256)), dim3(256), 0, h->stream, v.Pxg, v.nsplit_xg, quads, v.Usum);
+}
+void launch_fold_t(resnmtf_handle* h, const ViewState& v) {
+  if (!v.Tsum) return;
+  const int quads = v.m_pad * v.KP / 4;
+  hipLaunchKernelGGL(slab_fold_kernel, dim3(ceil_div(quads, 256)), dim3(256), 0, h->stream, v.Pxtf, v.nsplit_xtf, quads, v.Tsum);
+}
+// replicate_gs: the second half of the k x k job of EVERY view (update_s chain, update_lm, error, F coefficients)
+int launch_s_chain(resnmtf_handle* h, int sweep) {
+  SChainArgs a{};
+  const int V = h->V;
+  const ViewState& v0 = h->views[0];
+  a.k = v0.k; a.n_views = V; a.sweep = sweep;
+  a.sblocks = h->sblk_arena; a.sblock_stride = h->sblk_stride;
+  double sum_xi = 0.0;
+  for (double x : h->xi) sum_xi += x;
+  a.restricted = sum_xi != 0.0 ? 1 : 0;
+  for (int w = 0; w < V; ++w) {
+    const ViewState& vs = h->views[w];
+    a.S[w] = vs.S; a.lambda[w] = vs.lambda; a.mu[w] = vs.mu; a.Ma_F[w] = vs.Ma_F; a.Md_F[w] = vs.Md_F;
+    double sg = 0.0;
+    for (int c = 0; c < V; ++c) {
+      const double wgt = h->xi[(size_t)c + (size_t)w * V];                          // xi[c, w]
+      a.xi[c][w] = (c == w) ? 0.0 : wgt;
+      sg += wgt;
+    }
+    a.sigma[w] = sg;
+  }
+  a.err = h->err; a.err_stride = V; a.err_cap = h->err_cap; a.err_host = h->err_host_dev;
+  a.ctl = h->ctl; a.ctl_host = h->ctl_host_dev;
+  const size_t smem = kk_smem_bytes(v0.KP, 8);
+  switch (v0.NT) {
+    case 1: hipLaunchKernelGGL(s_chain_kernel<16>, dim3(V), dim3(512), smem, h->stream, a); break;
+    case 2: hipLaunchKernelGGL(s_chain_kernel<32>, dim3(V), dim3(512), smem, h->stream, a); break;
+    case 3: hipLaunchKernelGGL(s_chain_kernel<48>, dim3(V), dim3(512), smem, h->stream, a); break;
+    default: hipLaunchKernelGGL(s_chain_kernel<64>, dim3(V), dim3(512), smem, h->stream, a); break;
+  }
+  return RESNMTF_OK;
 }
 void enqueue_phase_g(resnmtf_handle* h, const ViewState& v, double tol, bool checked) {
   launch_pass(h, v, false, 1, tol, checked);
@@ -790,7 +839,22 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     if ((e = hipMalloc(&h->fblk_arena, h->fblk_arena_bytes)) != hipSuccess) return bail(e, "hipMalloc F exchange blocks");
     if ((e = hipMemset(h->fblk_arena, 0, h->fblk_arena_bytes)) != hipSuccess) return bail(e, "hipMemset F exchange blocks");
   }
-  size_t fblk_off = 0;
+  auto gblk_tsum_bytes = [](const ViewState& vs) { return ((size_t)vs.m_pad * vs.KP * sizeof(float) + 255) / 256 * 256; };
+  auto gblk_size = [&](const ViewState& vs) {
+    return (gblk_tsum_bytes(vs) + (2 * (size_t)vs.k * vs.k + (size_t)vs.k) * sizeof(double) + 255) / 256 * 256;
+  };
+  if (o.replicate_gs) {
+    if (!o.replicate_f) { g_create_error = "replicate_gs needs replicate_f"; resnmtf_destroy(h); return RESNMTF_ERR_INVALID; }
+    for (const auto& vs : h->views)
+      if (vs.k != h->views[0].k) { g_create_error = "replicate_gs needs the same k in every view"; resnmtf_destroy(h); return RESNMTF_ERR_INVALID; }
+    for (const auto& vs : h->views) h->gblk_arena_bytes += gblk_size(vs);
+    if ((e = hipMalloc(&h->gblk_arena, h->gblk_arena_bytes)) != hipSuccess) return bail(e, "hipMalloc G exchange blocks");
+    if ((e = hipMemset(h->gblk_arena, 0, h->gblk_arena_bytes)) != hipSuccess) return bail(e, "hipMemset G exchange blocks");
+    const size_t kk0 = (size_t)h->views[0].k * h->views[0].k;
+    h->sblk_stride = (5 * kk0 + 2 * (size_t)h->views[0].k + 1 + 31) / 32 * 32;
+    if ((e = dev_alloc_zero(&h->sblk_arena, h->sblk_stride * n_views)) != hipSuccess) return bail(e, "hipMalloc S exchange blocks");
+  }
+  size_t fblk_off = 0, gblk_off = 0;
   for (int v = 0; v < n_views; ++v) {
     ViewState& vs = h->views[v];
     const size_t kk = (size_t)vs.k * vs.k;
@@ -858,6 +922,23 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
         if (vs.kk_mode == 0 && (e = dev_alloc_zero(&vs.partF, (size_t)vs.nblkF * (kkp + vs.KP))) != hipSuccess) return bail(e, "hipMalloc partF");
       }
     }
+    if (o.replicate_gs) {
+      vs.gblk_bytes = gblk_size(vs);
+      char* base = static_cast<char*>(h->gblk_arena) + gblk_off;
+      gblk_off += vs.gblk_bytes;
+      vs.gblk = base;
+      vs.Tsum = reinterpret_cast<float*>(base);
+      vs.Ma_G = reinterpret_cast<double*>(base + gblk_tsum_bytes(vs));
+      vs.Md_G = vs.Ma_G + kk;
+      vs.mu = vs.Md_G + kk;
+      vs.sblk = h->sblk_arena + (size_t)v * h->sblk_stride;
+      if (!vs.owned) {                // (a G replica writes the same copies as the owner: nobody reads them here)
+        vs.g_replica = true;
+        if ((e = dev_alloc_zero(&vs.G32, (size_t)vs.m_pad * 64)) != hipSuccess) return bail(e, "hipMalloc G32");
+        if ((e = dev_alloc_zero(&vs.T32, (size_t)vs.m_pad * 64)) != hipSuccess) return bail(e, "hipMalloc T32");
+        if (vs.kk_mode == 0 && (e = dev_alloc_zero(&vs.partG, (size_t)vs.nblkG * (2 * kkp + vs.KP))) != hipSuccess) return bail(e, "hipMalloc partG");
+      }
+    }
     if (!vs.owned) continue;
     if ((e = dev_alloc_zero(&vs.Pxg, pxg_floats)) != hipSuccess) return bail(e, "hipMalloc Pxg");
     if (!o.replicate_f) {
@@ -865,7 +946,7 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
       for (double** pp : {&vs.Ma_F, &vs.Md_F})
         if ((e = dev_alloc_zero(pp, kk)) != hipSuccess) return bail(e, "hipMalloc kxk");
     }
-    if ((e = dev_alloc_zero(&vs.mu, (size_t)vs.k)) != hipSuccess) return bail(e, "hipMalloc mu");
+    if (!o.replicate_gs && (e = dev_alloc_zero(&vs.mu, (size_t)vs.k)) != hipSuccess) return bail(e, "hipMalloc mu");
     if ((e = dev_alloc_zero(&vs.xnorm2, 1)) != hipSuccess) return bail(e, "hipMalloc xnorm2");
     if ((e = dev_alloc_zero(&vs.X32, vs.x32_floats)) != hipSuccess) return bail(e, "hipMalloc X32");
     if ((e = dev_alloc_zero(&vs.Xt32, vs.xt32_floats)) != hipSuccess) return bail(e, "hipMalloc Xt32");
@@ -887,8 +968,11 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     }
     if ((e = dev_alloc_zero(&vs.cnt_xg, 4)) != hipSuccess) return bail(e, "hipMalloc cnt");
     if ((e = dev_alloc_zero(&vs.cnt_xtf, 4)) != hipSuccess) return bail(e, "hipMalloc cnt");
-    for (double** pp : {&vs.FtF, &vs.FtFS, &vs.Ma_G, &vs.Md_G})
+    for (double** pp : {&vs.FtF, &vs.FtFS})
       if ((e = dev_alloc_zero(pp, kk)) != hipSuccess) return bail(e, "hipMalloc kxk");
+    if (!o.replicate_gs)
+      for (double** pp : {&vs.Ma_G, &vs.Md_G})
+        if ((e = dev_alloc_zero(pp, kk)) != hipSuccess) return bail(e, "hipMalloc kxk");
     if ((e = dev_alloc_zero(&vs.cF, (size_t)vs.k)) != hipSuccess) return bail(e, "hipMalloc cF");
     if ((e = dev_alloc_zero(&vs.Pxtf, (size_t)vs.nsplit_xtf * vs.m_pad * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Pxtf");
     if ((e = dev_alloc_zero(&vs.Paux_xg, (size_t)3 * vs.nsaux_xg * 64 * vs.KP)) != hipSuccess) return bail(e, "hipMalloc Paux");
@@ -919,6 +1003,8 @@ int resnmtf_destroy(resnmtf_handle* h) {
   destroy_graphs(h);
   for (auto& v : h->views) free_view(v);
   if (h->fblk_arena) (void)hipFree(h->fblk_arena);
+  if (h->gblk_arena) (void)hipFree(h->gblk_arena);
+  if (h->sblk_arena) (void)hipFree(h->sblk_arena);
   if (h->ctl) (void)hipFree(h->ctl);
   if (h->err) (void)hipFree(h->err);
   if (h->err_host) (void)hipHostFree(h->err_host);
@@ -1590,7 +1676,7 @@ static int build_args(resnmtf_handle* h) {
   for (int v = 0; v < V; ++v) {
     ViewState& vs = h->views[v];
     if (!vs.has_factors) return h->fail(RESNMTF_ERR_STATE, "set_factors missing for a view");
-    if (!vs.owned && !vs.f_replica) continue;
+    if (!vs.owned && !vs.f_replica && !vs.g_replica) continue;
     // --- F update (R/update_steps.r:141-165)
     UpdateArgs& f = vs.argF;
     f = UpdateArgs{};
@@ -1615,7 +1701,33 @@ static int build_args(resnmtf_handle* h) {
         c.W = h->views[i].F; c.map = mp.identity ? nullptr : mp.dev; c.weight = wgt; c.n_other = (double)h->views[i].n;
       }
     }
-    if (!vs.owned) continue;       // (an F replica only ever runs PHASE_F)
+    // --- G update (R/update_steps.r:180-207); branch on the WHOLE psi matrix (:190)
+    if (vs.owned || vs.g_replica) {
+    UpdateArgs& g = vs.argG;
+    g = UpdateArgs{};
+    g.len = vs.m; g.k = vs.k; g.W = vs.G; g.W32 = vs.G32; g.Wk = vs.Gk; g.ld32 = vs.kk_mode == 0 ? vs.KP : 64; g.kpack32 = vs.half ? 1 : 0;
+    g.P = vs.Pxtf; g.nsplit = vs.nsplit_xtf; g.cols_pad = vs.m_pad;
+    if (vs.Tsum) { g.P = vs.Tsum; g.nsplit = 1; }      // replicate_gs: the folded slab of the exchange block
+    g.Ma = vs.Ma_G; g.Md = vs.Md_G; g.lm = vs.mu; g.T32 = vs.T32; g.part = vs.partG;
+    g.rows_per_block = vs.rpbG; g.ctl = h->ctl;
+    {
+      double sigma = 0.0;
+      for (int i = 0; i < V; ++i) sigma += h->psi[(size_t)i + (size_t)v * V];     // sum(psi[, v])  (:195,:200)
+      g.restricted = (sum_psi != 0.0) ? 1 : 0;
+      g.sigma = sigma;
+      g.n_couple = 0;
+      for (int i = 0; i < V && g.restricted; ++i) {
+        const double wgt = h->psi[(size_t)i + (size_t)v * V];
+        if (wgt == 0.0 || i == v) continue;
+        const SharedMap& mp = vs.col_map[i];
+        if (!mp.set || mp.count < 0) continue;
+        if (h->views[i].k != vs.k) return h->fail(RESNMTF_ERR_INVALID, "psi-coupled views need equal k");
+        CoupleDesc& c = g.couple[g.n_couple++];
+        c.W = h->views[i].G; c.map = mp.identity ? nullptr : mp.dev; c.weight = wgt; c.n_other = (double)h->views[i].m;
+      }
+    }
+    }
+    if (!vs.owned) continue;       // (replicas only ever run the update kernels)
     if (!vs.has_x) return h->fail(RESNMTF_ERR_STATE, "set_view missing for an owned view");
     // --- streaming passes
     PassArgs& xg = vs.passXG;
@@ -1636,29 +1748,6 @@ static int build_args(resnmtf_handle* h) {
     xt.aux[0] = vs.F32; xt.aux[1] = nullptr; xt.naux = 2;                          // F^T F, colSums(F)
     xt.Paux = vs.Paux_xtf; xt.rows_per_split_aux = vs.rpsaux_xtf; xt.nsplit_aux = vs.nsaux_xtf; xt.aux_cnt = vs.cnt_xtf;
     xt.ctl = h->ctl;
-    // --- G update (R/update_steps.r:180-207); branch on the WHOLE psi matrix (:190)
-    UpdateArgs& g = vs.argG;
-    g = UpdateArgs{};
-    g.len = vs.m; g.k = vs.k; g.W = vs.G; g.W32 = vs.G32; g.Wk = vs.Gk; g.ld32 = vs.kk_mode == 0 ? vs.KP : 64; g.kpack32 = vs.half ? 1 : 0;
-    g.P = vs.Pxtf; g.nsplit = vs.nsplit_xtf; g.cols_pad = vs.m_pad;
-    g.Ma = vs.Ma_G; g.Md = vs.Md_G; g.lm = vs.mu; g.T32 = vs.T32; g.part = vs.partG;
-    g.rows_per_block = vs.rpbG; g.ctl = h->ctl;
-    {
-      double sigma = 0.0;
-      for (int i = 0; i < V; ++i) sigma += h->psi[(size_t)i + (size_t)v * V];     // sum(psi[, v])  (:195,:200)
-      g.restricted = (sum_psi != 0.0) ? 1 : 0;
-      g.sigma = sigma;
-      g.n_couple = 0;
-      for (int i = 0; i < V && g.restricted; ++i) {
-        const double wgt = h->psi[(size_t)i + (size_t)v * V];
-        if (wgt == 0.0 || i == v) continue;
-        const SharedMap& mp = vs.col_map[i];
-        if (!mp.set || mp.count < 0) continue;
-        if (h->views[i].k != vs.k) return h->fail(RESNMTF_ERR_INVALID, "psi-coupled views need equal k");
-        CoupleDesc& c = g.couple[g.n_couple++];
-        c.W = h->views[i].G; c.map = mp.identity ? nullptr : mp.dev; c.weight = wgt; c.n_other = (double)h->views[i].m;
-      }
-    }
     // --- k x k side kernels
     KKFArgs& kf = vs.argKF;
     kf = KKFArgs{};
@@ -1672,6 +1761,7 @@ static int build_args(resnmtf_handle* h) {
     ks.xnorm2 = vs.xnorm2;
     ks.err = h->err; ks.err_stride = V; ks.err_col = v; ks.err_cap = h->err_cap;
     ks.err_host = h->err_host_dev; ks.ctl_host = h->ctl_host_dev;
+    ks.sblock = vs.sblk;
     ks.ctl = h->ctl; ks.last_view = (v == h->last_owned) ? 1 : 0; ks.n_views = V; ks.tol = -1.0;
     {
       double sigma = 0.0;
@@ -1737,8 +1827,13 @@ int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep) {
   if (int rc = check_view(h, v)) return rc;
   if (!h->prepared) return h->fail(RESNMTF_ERR_STATE, "resnmtf_prepare has not been called");
   const ViewState& vs = h->views[v];
-  if (!vs.owned && !(vs.f_replica && phase == RESNMTF_PHASE_F) && phase != RESNMTF_PHASE_F_ALL && phase != RESNMTF_PHASE_LOCAL_SWEEP)
+  if (!vs.owned && !(vs.f_replica && phase == RESNMTF_PHASE_F) && phase != RESNMTF_PHASE_F_ALL && phase != RESNMTF_PHASE_LOCAL_SWEEP &&
+      phase != RESNMTF_PHASE_G_ALL && phase != RESNMTF_PHASE_S_ALL)
     return h->fail(RESNMTF_ERR_STATE, "phase on a view this handle does not own");
+  if (phase >= RESNMTF_PHASE_XTF && phase <= RESNMTF_PHASE_S_ALL && !h->opt.replicate_gs)
+    return h->fail(RESNMTF_ERR_STATE, "this phase needs a handle created with replicate_gs = 1");
+  if (h->opt.replicate_gs && (phase == RESNMTF_PHASE_G || phase == RESNMTF_PHASE_LOCAL_SWEEP))
+    return h->fail(RESNMTF_ERR_STATE, "replicate_gs: use PHASE_XTF / G_ALL / XG / S_ALL instead of PHASE_G");
   if (sweep < 0) return h->fail(RESNMTF_ERR_INVALID, "negative sweep index");
   if (sweep >= h->err_cap) return h->fail(RESNMTF_ERR_STATE, "sweep beyond the reserved error buffer (resnmtf_reserve_sweeps)");
   h->resume_ok = false;
@@ -1751,6 +1846,15 @@ int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep) {
     case RESNMTF_PHASE_LOCAL_SWEEP:
       if (int rc = launch_local_sweep(h)) return rc;
       break;
+    case RESNMTF_PHASE_XTF: launch_pass(h, vs, false, 1, -1.0, false); launch_fold_t(h, vs); break;
+    case RESNMTF_PHASE_G_ALL:
+      for (const auto& w : h->views)
+        if (w.owned || w.g_replica) launch_update(h, w, 1, false);
+      break;
+    case RESNMTF_PHASE_XG: launch_pass(h, vs, true, 1, -1.0, false); launch_fold(h, vs); break;
+    case RESNMTF_PHASE_S_ALL:
+      if (int rc = launch_s_chain(h, sweep)) return rc;
+      break;
     default: return h->fail(RESNMTF_ERR_INVALID, "unknown phase");
   }
   HIP_TRY(h, hipGetLastError());
@@ -1762,6 +1866,7 @@ int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, doubl
   if (!h) return RESNMTF_ERR_INVALID;
   if (iters_done) *iters_done = 0;
   if (!h->all_owned) return h->fail(RESNMTF_ERR_STATE, "resnmtf_run needs a handle that owns every view; use the phase API");
+  if (h->opt.replicate_gs) return h->fail(RESNMTF_ERR_STATE, "resnmtf_run does not drive the replicated G / S chains (replicate_gs); use the phase API");
   if (n_iters < 0) return h->fail(RESNMTF_ERR_INVALID, "n_iters must be >= 0");
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
   int total;
@@ -1935,6 +2040,18 @@ int resnmtf_factor_device_ptr(resnmtf_handle* h, int v, int which, void** ptr, s
     case RESNMTF_FACTOR_FBLOCK_ALL:
       if (!h->fblk_arena) return h->fail(RESNMTF_ERR_STATE, "no F exchange blocks: create the handle with replicate_f = 1");
       *ptr = h->fblk_arena; *bytes = h->fblk_arena_bytes; break;
+    case RESNMTF_FACTOR_GBLOCK:
+      if (!vs.gblk) return h->fail(RESNMTF_ERR_STATE, "no G exchange block: create the handle with replicate_gs = 1");
+      *ptr = vs.gblk; *bytes = vs.gblk_bytes; break;
+    case RESNMTF_FACTOR_GBLOCK_ALL:
+      if (!h->gblk_arena) return h->fail(RESNMTF_ERR_STATE, "no G exchange blocks: create the handle with replicate_gs = 1");
+      *ptr = h->gblk_arena; *bytes = h->gblk_arena_bytes; break;
+    case RESNMTF_FACTOR_SBLOCK:
+      if (!vs.sblk) return h->fail(RESNMTF_ERR_STATE, "no S exchange block: create the handle with replicate_gs = 1");
+      *ptr = vs.sblk; *bytes = h->sblk_stride * sizeof(double); break;
+    case RESNMTF_FACTOR_SBLOCK_ALL:
+      if (!h->sblk_arena) return h->fail(RESNMTF_ERR_STATE, "no S exchange blocks: create the handle with replicate_gs = 1");
+      *ptr = h->sblk_arena; *bytes = h->sblk_stride * sizeof(double) * h->V; break;
     default: return h->fail(RESNMTF_ERR_INVALID, "unknown factor selector");
   }
   return RESNMTF_OK;

@@ -41,7 +41,7 @@ class Engine:
                  time_kernels: bool = False, pass_waves: int = 0, pass_splits_xg: int = 0,
                  pass_splits_xtf: int = 0, pass_lds_pad_kb: int = 0, update_blocks: int = 0, no_pitch_pad: bool = False,
                  kk_mode: int = 0, bf16_split: int = 0, replicate_f: bool = False, no_f_chain: bool = False,
-                 x_half: int = 0, half_unroll: int = 0):
+                 x_half: int = 0, half_unroll: int = 0, replicate_gs: bool = False):
         self._lib = _lib.load()
         self.n_views = len(n_rows)
         self.n_rows = [int(x) for x in n_rows]
@@ -68,6 +68,7 @@ class Engine:
         opts.no_f_chain = 1 if no_f_chain else 0
         opts.x_half = int(x_half)
         opts.half_unroll = int(half_unroll)
+        opts.replicate_gs = 1 if replicate_gs else 0
         nr = np.asarray(self.n_rows, dtype=np.int32)
         nc = np.asarray(self.n_cols, dtype=np.int32)
         kk = np.asarray(self.k, dtype=np.int32)

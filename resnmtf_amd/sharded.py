@@ -55,11 +55,13 @@ from typing import Callable, Dict, List, Optional, Sequence
 import numpy as np
 
 from . import naming
-from ._lib import (FACTOR_F, FACTOR_FBLOCK, FACTOR_FBLOCK_ALL, FACTOR_G, FACTOR_S, PHASE_F, PHASE_F_ALL, PHASE_G,
-                   PHASE_LOCAL_SWEEP, PHASE_S)
+from ._lib import (FACTOR_F, FACTOR_FBLOCK, FACTOR_FBLOCK_ALL, FACTOR_G, FACTOR_GBLOCK, FACTOR_GBLOCK_ALL, FACTOR_S,
+                   FACTOR_SBLOCK, FACTOR_SBLOCK_ALL, PHASE_F, PHASE_F_ALL, PHASE_G, PHASE_G_ALL, PHASE_LOCAL_SWEEP, PHASE_S,
+                   PHASE_S_ALL, PHASE_XG, PHASE_XTF)
 from .synth import Problem, planted_view, random_init
 
-_WHICH = {"F": FACTOR_F, "G": FACTOR_G, "S": FACTOR_S, "FBLOCK": FACTOR_FBLOCK, "FBLOCK_ALL": FACTOR_FBLOCK_ALL}
+_WHICH = {"F": FACTOR_F, "G": FACTOR_G, "S": FACTOR_S, "FBLOCK": FACTOR_FBLOCK, "FBLOCK_ALL": FACTOR_FBLOCK_ALL,
+          "GBLOCK": FACTOR_GBLOCK, "GBLOCK_ALL": FACTOR_GBLOCK_ALL, "SBLOCK": FACTOR_SBLOCK, "SBLOCK_ALL": FACTOR_SBLOCK_ALL}
 
 
 def exchange_plan(n_views: int, owner_of: Sequence[int], phi, xi, psi, row_shared, col_shared) -> List[Dict[str, bool]]:
@@ -115,6 +117,7 @@ class _CudaBlob:
 
 class HipEngineAdapter:
     """What the driver needs from an engine, on top of ``resnmtf_amd.engine.Engine``."""
+    supports_replicated_gs = True
 
     def __init__(self, engine):
         self.e = engine
@@ -155,7 +158,7 @@ class HipEngineAdapter:
 
 
 def make_hip_engine(prob: Problem, owned: Sequence[bool], device_index: int, stream: int,
-                    replicate_f: bool = False, **engine_opts) -> HipEngineAdapter:
+                    replicate_f: bool = False, replicate_gs: bool = False, **engine_opts) -> HipEngineAdapter:
     """Engine for this rank: data only for owned views, factor mirrors for the others, every kernel
     on the given HIP stream -- the torch stream the driver makes current around its broadcasts, so
     that torch.distributed orders them against the kernels.  (The legacy NULL stream must not be
@@ -167,7 +170,7 @@ def make_hip_engine(prob: Problem, owned: Sequence[bool], device_index: int, str
     n_v = len(prob.init_f)
     shapes = prob.extras["shapes"]
     eng = Engine([s[0] for s in shapes], [s[1] for s in shapes], [prob.k] * n_v, owned=list(owned),
-                 device_id=device_index, stream=stream, replicate_f=replicate_f, **engine_opts)
+                 device_id=device_index, stream=stream, replicate_f=replicate_f, replicate_gs=replicate_gs, **engine_opts)
     for v in range(n_v):
         if owned[v]:
             eng.set_view(v, prob.data[v])
@@ -239,6 +242,19 @@ class ShardedSweep:
         if replicate_f == "force":    # rehearsal of the replicated path with fewer ranks than it needs (bench.py, one GPU)
             rep = [True] * self.n_views
         self.replicated = rep if (replicate_f and any(rep)) else [False] * self.n_views
+        # Replicated G and S chains (psi / xi coupling across ranks, one view per rank, equal k): every rank runs the G
+        # and S updates of EVERY view from all-gathered inputs and streams only its own X -- the two passes of all ranks
+        # then run at the same time, where ordered broadcasts of G_v / S_v would serialise whole ranks behind each other
+        # (G_v' needs G_w' of every w < v, R/update_steps.r:195-204; S likewise, :231-237)
+        want_gs = engine_opts.pop("replicate_gs", None)
+        gs_coupled = any(p["G"] or p["S"] for p in self.plan)
+        k_all = [f.shape[1] for f in prob.init_f]
+        can_gs = (bool(replicate_f) and self.owner_of == list(range(world)) and len(set(k_all)) == 1 and self.n_views == world)
+        self.replicate_gs = bool(can_gs and (gs_coupled if want_gs is None else want_gs))
+        if self.replicate_gs:
+            self.replicated = [True] * self.n_views
+            for v in range(self.n_views):
+                self.plan[v]["G"] = self.plan[v]["S"] = False
         if any(self.replicated):      # the F blocks of replicated views travel instead of their F
             for v in range(self.n_views):
                 if self.replicated[v]:
@@ -260,10 +276,15 @@ class ShardedSweep:
             self._tstream = torch.cuda.Stream(device=device_index)
             self._xstream = self._tstream if self._serial else torch.cuda.Stream(device=device_index)
             self.engine = make_hip_engine(prob, self.owned, device_index, self._tstream.cuda_stream,
-                                          replicate_f=any(self.replicated), **engine_opts)
+                                          replicate_f=any(self.replicated), replicate_gs=self.replicate_gs, **engine_opts)
         self.sweeps_done = 0
         self._prepared = False
+        if self.replicate_gs and not getattr(self.engine, "supports_replicated_gs", engine is None and engine_factory is None):
+            raise ValueError("replicate_gs needs an engine with the block phases (PHASE_XTF / G_ALL / XG / S_ALL)")
         self._allgather_blocks = self._can_allgather(engine_opts_allgather)
+        if self.replicate_gs and self._tstream is not None:       # three collectives between dependent steps: one stream
+            self._serial = True
+            self._xstream = self._tstream
         # all-gather layout: the exchange sits between two dependent steps of the sweep (nothing to overlap it
         # with), so it is issued on the compute stream itself -- measured with one rank on RCCL: 54.6 us per
         # sweep against 90.0 us through a second stream and its event edges
@@ -316,6 +337,35 @@ class ShardedSweep:
                 for v in range(self.n_views):
                     self._ev_recv[(v, "FBLOCK")] = ev
             ev.record(self._xstream)
+
+    def _gather_blocks(self, kind: str):
+        """Every rank's exchange block of one kind ("FBLOCK", "GBLOCK", "SBLOCK") to every rank: one in-place all-gather
+        over the library's arena when the blocks have one size (RCCL), else -- unequal views, or gloo in the tests and
+        rehearsals -- the same bytes by one broadcast per block."""
+        blocks = [self.engine.factor_tensor(v, kind) for v in range(self.n_views)]
+        if self._tstream is not None and self.dist.get_backend(self.group) == "nccl":
+            arena = self.engine.factor_tensor(0, kind + "_ALL")
+            size = blocks[0].numel()
+            if arena.numel() == size * self.n_views and all(b.numel() == size for b in blocks):
+                self.dist.all_gather_into_tensor(arena, blocks[self.rank], group=self.group)
+                return
+        for v in range(self.n_views):
+            self.dist.broadcast(blocks[v], src=self.owner_of[v], group=self.group)
+
+    def _sweep_replicated_gs(self, t: int):
+        """One sweep with all three chains replicated (R/update_steps.r:282-314 in the reference's order):
+            F chain (every view, every rank)  ->  Xt.F pass of the own view  ->  [T blocks]  ->  G chain (every view)
+            ->  X.G' pass of the own view + first half of its k x k job  ->  [S blocks]  ->  S chain, lambda, mu, error,
+            F coefficients (every view)  ->  [U blocks]"""
+        r = self.rank
+        self.engine.phase(r, PHASE_F_ALL, t)
+        self.engine.phase(r, PHASE_XTF, t)
+        self._gather_blocks("GBLOCK")
+        self.engine.phase(r, PHASE_G_ALL, t)
+        self.engine.phase(r, PHASE_XG, t)
+        self._gather_blocks("SBLOCK")
+        self.engine.phase(r, PHASE_S_ALL, t)
+        self._gather_blocks("FBLOCK")
 
     def _bcast(self, v: int, which: str):
         t = self.engine.factor_tensor(v, which)
@@ -428,7 +478,10 @@ class ShardedSweep:
             self.engine.prepare()
             self._prepared = True
             self._gs_exchanged = any(p["G"] or p["S"] for p in self.plan)
-            if any(self.replicated):      # the run prologue filled the owners' blocks: hand them round once
+            if self.replicate_gs:         # F blocks (U, coefficients, lambda) and G blocks (mu of every view)
+                self._gather_blocks("FBLOCK")
+                self._gather_blocks("GBLOCK")
+            elif any(self.replicated):    # the run prologue filled the owners' blocks: hand them round once
                 if self._tstream is not None and self._xstream is not self._tstream:
                     self._ev_g = self._next_event()
                     self._ev_g.record(self._tstream)
@@ -443,6 +496,10 @@ class ShardedSweep:
         two_streams = self._tstream is not None and self._xstream is not self._tstream
         for _ in range(n_sweeps):
             t = self.sweeps_done
+            if self.replicate_gs:
+                self._sweep_replicated_gs(t)
+                self.sweeps_done += 1
+                continue
             # all-gather layout: every F update of the sweep first, as ONE phase (one launch when the views share
             # their rows in the same order).  Legal hoist: F_w' reads neither G nor S of this sweep.
             hoist = self._allgather_blocks

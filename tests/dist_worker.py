@@ -79,6 +79,152 @@ class OracleEngine:
         return f[0], s[0], g[0], rc[0], cc[0]
 
 
+class OracleBlockEngine(OracleEngine):
+    """Stand-in for the replicated-chains layout (replicate_gs): the exchange blocks are CPU tensors holding what the
+    library's blocks hold in exact fp64 -- F block [U = X G | S | G^T G | lambda], G block [T = X^T F' | S | F'^T F' | mu],
+    S block [S old | F'^T X G' | F'^T F' | G'^T G'] -- and the _ALL phases evaluate the reference's rules for EVERY view
+    from them, with the reference's association order (R/update_steps.r:141-251 restated on the products instead of X:
+    x %*% g -> U, crossprod(x, f) -> T, crossprod(f, x) %*% g -> T^T g)."""
+    supports_replicated_gs = True
+
+    def __init__(self, prob, owned):
+        super().__init__(prob, owned)
+        t = self.torch
+        k = prob.k
+        self.nm = [(f.shape[0], g.shape[0]) for f, g in zip(prob.init_f, prob.init_g)]
+        self.fblk = [t.zeros(n * k + 2 * k * k + k, dtype=t.float64) for n, _ in self.nm]
+        self.gblk = [t.zeros(m * k + 2 * k * k + k, dtype=t.float64) for _, m in self.nm]
+        self.sblk = [t.zeros(4 * k * k, dtype=t.float64) for _ in self.nm]
+        self.lam_all = [t.tensor(f.sum(0)) for f in prob.init_f]          # every rank tracks lambda / mu of every view
+        self.mu_all = [t.tensor(g.sum(0)) for g in prob.init_g]
+        self.k = k
+
+    def prepare(self):                                                     # run prologue of the owned views: U = X G
+        for v in range(self.n_v):
+            if self.owned[v]:
+                self._fill_fblock(v)
+
+    def _fill_fblock(self, v):
+        k, (n, _) = self.k, self.nm[v]
+        g, sm = self.G[v].numpy(), self.S[v].numpy()
+        blk = self.fblk[v].numpy()
+        blk[:n * k] = (self.prob.data[v] @ g).ravel()
+        blk[n * k:n * k + k * k] = sm.ravel()
+        blk[n * k + k * k:n * k + 2 * k * k] = (g.T @ g).ravel()
+        blk[n * k + 2 * k * k:] = self.lam_all[v].numpy()
+
+    def factor_tensor(self, v, which):
+        if which == "FBLOCK":
+            return self.fblk[v]
+        if which == "GBLOCK":
+            return self.gblk[v]
+        if which == "SBLOCK":
+            return self.sblk[v]
+        if which.endswith("_ALL"):
+            raise RuntimeError("no arena in the stand-in")
+        return super().factor_tensor(v, which)
+
+    def phase(self, v, ph, sweep):
+        from resnmtf_amd._lib import PHASE_F_ALL, PHASE_G_ALL, PHASE_S_ALL, PHASE_XG, PHASE_XTF
+        O, p, k = self.O, self.prob, self.k
+        if ph == PHASE_F_ALL:                                               # update_f of every view, R/update_steps.r:141-165
+            for w in range(self.n_v):
+                n = self.nm[w][0]
+                blk = self.fblk[w].numpy()
+                u = blk[:n * k].reshape(n, k); sm = blk[n * k:n * k + k * k].reshape(k, k)
+                gtg = blk[n * k + k * k:n * k + 2 * k * k].reshape(k, k); lam = blk[n * k + 2 * k * k:]
+                fl = [t.numpy() for t in self.F]
+                cur = fl[w]
+                numerator = u @ sm.T                                         # :146
+                denominator = (cur @ sm) @ (gtg @ sm.T)                      # :147-148
+                lam_mat = 0.5 * np.tile(lam, (n, 1))                         # :151
+                phi_vec = p.phi[:, w]
+                if phi_vec.sum() == 0:                                       # :152
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        ratio = numerator / (denominator + lam_mat)
+                    ratio[np.isnan(ratio)] = 1.0
+                    new = cur * ratio
+                else:
+                    num_mat_prod = O.star_prod_relevant(phi_vec, fl, cur, self.row_idx[w], p.row_names[w], p.row_names)
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        new = cur * ((numerator + num_mat_prod) / (denominator + phi_vec.sum() * cur + lam_mat))
+                self.F[w].copy_(self.torch.from_numpy(np.abs(new)))
+        elif ph == PHASE_XTF:                                               # T = X^T F', F'^T F' of the own view
+            m = self.nm[v][1]
+            f = self.F[v].numpy()
+            blk = self.gblk[v].numpy()
+            blk[:m * k] = (p.data[v].T @ f).ravel()
+            blk[m * k:m * k + k * k] = self.S[v].numpy().ravel()
+            blk[m * k + k * k:m * k + 2 * k * k] = (f.T @ f).ravel()
+            blk[m * k + 2 * k * k:] = self.mu_all[v].numpy()
+        elif ph == PHASE_G_ALL:                                             # update_g of every view, R/update_steps.r:180-207
+            for w in range(self.n_v):
+                m = self.nm[w][1]
+                blk = self.gblk[w].numpy()
+                tt = blk[:m * k].reshape(m, k); sm = blk[m * k:m * k + k * k].reshape(k, k)
+                ftf = blk[m * k + k * k:m * k + 2 * k * k].reshape(k, k); mu = blk[m * k + 2 * k * k:]
+                gl = [t.numpy() for t in self.G]
+                cur = gl[w]
+                numerator = tt @ sm                                          # :185
+                denominator = (cur @ sm.T) @ (ftf @ sm)                      # :186-187
+                mu_mat = 0.5 * np.tile(mu, (m, 1))                           # :188
+                if p.psi.sum() == 0:                                         # :190 (whole matrix)
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        ratio = numerator / (denominator + mu_mat)
+                    ratio[np.isnan(ratio)] = 1.0
+                    new = cur * ratio
+                else:
+                    psi_vec = p.psi[:, w]
+                    num_mat_prod = O.star_prod_relevant(psi_vec, gl, cur, self.col_idx[w], p.col_names[w], p.col_names)
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        new = cur * ((numerator + num_mat_prod) / (denominator + psi_vec.sum() * cur + mu_mat))
+                self.G[w].copy_(self.torch.from_numpy(np.abs(new)))
+        elif ph == PHASE_XG:                                                # S block + the U of the next F update
+            f, g = self.F[v].numpy(), self.G[v].numpy()
+            m = self.nm[v][1]
+            tt = self.gblk[v].numpy()[:m * k].reshape(m, k)
+            blk = self.sblk[v].numpy()
+            blk[:k * k] = self.S[v].numpy().ravel()
+            blk[k * k:2 * k * k] = ((f.T @ p.data[v]) @ g).ravel()           # :223
+            blk[2 * k * k:3 * k * k] = (f.T @ f).ravel()
+            blk[3 * k * k:] = (g.T @ g).ravel()
+            assert tt.shape == (m, k)
+            n = self.nm[v][0]
+            self.fblk[v].numpy()[:n * k] = (p.data[v] @ g).ravel()
+        elif ph == PHASE_S_ALL:                                             # update_s, update_lm of every view; error of the own
+            olds = [self.sblk[w].numpy()[:k * k].reshape(k, k).copy() for w in range(self.n_v)]
+            run = list(olds)
+            for w in range(self.n_v):
+                blk = self.sblk[w].numpy()
+                nn = blk[k * k:2 * k * k].reshape(k, k); ftf = blk[2 * k * k:3 * k * k].reshape(k, k); gtg = blk[3 * k * k:].reshape(k, k)
+                cur = run[w]
+                denominator = (ftf @ cur) @ gtg                              # :224
+                if p.xi.sum() == 0:                                          # :226
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        ratio = nn / denominator
+                    ratio[np.isnan(ratio)] = 1.0
+                    new = cur * ratio
+                else:
+                    xi_vec = p.xi[:, w]
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        new = cur * ((nn + O.star_prod(xi_vec, run)) / (denominator + xi_vec.sum() * cur))
+                run[w] = np.abs(new)
+                self.S[w].copy_(self.torch.from_numpy(run[w]))
+                self.lam_all[w] = self.lam_all[w] * self.F[w].sum(0)        # :249-251, :312-313
+                self.mu_all[w] = self.mu_all[w] * self.G[w].sum(0)
+                n = self.nm[w][0]
+                fb = self.fblk[w].numpy()
+                fb[n * k:n * k + k * k] = run[w].ravel()
+                fb[n * k + k * k:n * k + 2 * k * k] = gtg.ravel()
+                fb[n * k + 2 * k * k:] = self.lam_all[w].numpy()
+                if self.owned[w]:
+                    x = p.data[w]
+                    x_hat = (self.F[w].numpy() @ run[w]) @ self.G[w].numpy().T
+                    self.errs[w].append(np.linalg.norm(x - x_hat, "fro") ** 2 / self.norms[w])
+        else:
+            raise ValueError(f"phase {ph} is not part of the replicated-chains layout")
+
+
 def build_problem():
     """3 views, phi + psi + xi coupled, rows/columns partially shared at different positions."""
     from resnmtf_amd.synth import Problem, planted_view, random_init
@@ -118,12 +264,22 @@ def build_problem_one_view_per_rank(world=2, identity=False, xi=0.4):
     return prob
 
 
+def build_problem_gs(world):
+    """One view per rank, phi + psi + xi all coupling across ranks, rows AND columns shared in part and at different
+    positions, a different weight per pair (tests/helpers.py coupled_problem): the replicated-chains layout."""
+    from helpers import coupled_problem
+    shapes = [(96 + 8 * v, 72 - 8 * (v % 2)) for v in range(world)]
+    prob = coupled_problem(shapes, 5, seed=31 + world, phi_w=1.5, psi_w=1.0, xi_w=0.4)
+    prob.extras["shapes"] = shapes
+    return prob
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rank", type=int, required=True)
     ap.add_argument("--world", type=int, required=True)
     ap.add_argument("--port", type=int, required=True)
-    ap.add_argument("--mode", choices=["cpu", "gpu", "gpu_norep", "gpu_allgather", "gpu_chain", "gpu_chain_off", "gpu_graph1"], required=True)
+    ap.add_argument("--mode", choices=["cpu", "cpu_gs", "gpu", "gpu_gs", "gpu_norep", "gpu_allgather", "gpu_chain", "gpu_chain_off", "gpu_graph1"], required=True)
     ap.add_argument("--sweeps", type=int, default=12)
     ap.add_argument("--xi", type=float, default=0.4)
     ap.add_argument("--out", required=True)
@@ -154,11 +310,20 @@ def main():
         return
     dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
     one_per_rank = a.mode in ("gpu_allgather", "gpu_chain", "gpu_chain_off")
-    prob = build_problem_one_view_per_rank(a.world, identity=a.mode != "gpu_allgather", xi=a.xi) if one_per_rank else build_problem()
+    gs = a.mode in ("cpu_gs", "gpu_gs")
+    prob = (build_problem_gs(a.world) if gs else
+            build_problem_one_view_per_rank(a.world, identity=a.mode != "gpu_allgather", xi=a.xi) if one_per_rank else build_problem())
     n_v = len(prob.init_f)
     owner_of = [v % a.world for v in range(n_v)]
     if a.mode == "cpu":
         drv = sharded.ShardedSweep(prob, owner_of, a.rank, a.world, engine_factory=lambda p, owned: OracleEngine(p, owned))
+    elif a.mode == "cpu_gs":
+        drv = sharded.ShardedSweep(prob, owner_of, a.rank, a.world, engine_factory=lambda p, owned: OracleBlockEngine(p, owned),
+                                   replicate_f=True)
+        assert drv.replicate_gs
+    elif a.mode == "gpu_gs":
+        drv = sharded.ShardedSweep(prob, owner_of, a.rank, a.world, device_index=0)
+        assert drv.replicate_gs and all(drv.replicated)
     else:
         opts = {"no_f_chain": True} if a.mode == "gpu_chain_off" else {}
         drv = sharded.ShardedSweep(prob, owner_of, a.rank, a.world, device_index=0, replicate_f=(a.mode != "gpu_norep"), **opts)
@@ -167,10 +332,11 @@ def main():
     drv.run(a.sweeps // 2)
     drv.run(a.sweeps - a.sweeps // 2)          # two calls: state carries over
     mirrors_ok = True
-    if a.mode != "cpu":                          # every rank's copy of every F must be bitwise the owner's
+    if a.mode not in ("cpu", "cpu_gs"):          # every rank's copy of every F (G, S: replicated chains) must be bitwise the owner's
         import torch
         drv.engine.synchronize(); torch.cuda.synchronize()
-        mine = [drv.engine.factor_tensor(v, "F").cpu().numpy().tobytes() for v in range(n_v)]
+        kinds = ("F", "G", "S") if gs else ("F",)
+        mine = [b"".join(drv.engine.factor_tensor(v, kd).cpu().numpy().tobytes() for kd in kinds) for v in range(n_v)]
         allf = [None] * a.world
         dist.all_gather_object(allf, mine)
         mirrors_ok = all(allf[r][v] == allf[owner_of[v]][v] for r in range(a.world) for v in range(n_v))

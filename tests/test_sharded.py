@@ -223,3 +223,43 @@ def test_f_chain_eight_view_instantiation_one_process(views):
     for v in range(views):
         assert np.isfinite(out[False][v]).all() and out[False][v].max() > 0
         assert np.array_equal(out[False][v], out[True][v]), f"view {v}"
+
+
+def oracle_reference_gs(world, sweeps=12):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_worker
+    from oracle import resnmtf_oracle as O
+    prob = dist_worker.build_problem_gs(world)
+    return O.res_nmtf_inner(prob.data, prob.init_f, prob.init_s, prob.init_g, prob.phi, prob.xi, prob.psi,
+                            row_names=prob.row_names, col_names=prob.col_names, n_iters=sweeps)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_replicated_chains_schedule_matches_oracle_gloo_cpu(tmp_path, world):
+    """phi + psi + xi coupling across ranks, one view per rank: the driver's replicated-chains sweep (F chain, own Xt.F,
+    [T blocks], G chain, own X.G, [S blocks], S chain, [U blocks]) with a stand-in engine in exact fp64 reproduces the
+    sequential oracle (R/update_steps.r:282-314) to rounding of the re-associated products only."""
+    got = launch("cpu_gs", tmp_path, world=world)
+    ref = oracle_reference_gs(world)
+    np.testing.assert_allclose(got["all_error"], ref["All_Error"], rtol=1e-10, atol=1e-12)
+    for v in range(world):
+        assert rel_fro(got[f"output_f{v}"], ref["output_f"][v]) < 1e-11
+        assert rel_fro(got[f"output_g{v}"], ref["output_g"][v]) < 1e-11
+        assert rel_fro(got[f"output_s{v}"], ref["output_s"][v]) < 1e-11
+        assert np.array_equal(got[f"row_clusters{v}"], ref["row_clusters"][v])
+        assert np.array_equal(got[f"col_clusters{v}"], ref["col_clusters"][v])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_sharded_hip_replicated_g_and_s_chains(tmp_path, world):
+    """The same layout with the real HIP engine (ranks share the one GPU of the box, gloo): results against the oracle,
+    and every rank's copy of every F, G and S bitwise the owner's."""
+    got = launch("gpu_gs", tmp_path, world=world)
+    assert bool(got["mirrors_ok"])
+    ref = oracle_reference_gs(world)
+    np.testing.assert_allclose(got["all_error"], ref["All_Error"], atol=2e-5, rtol=1e-4)
+    for v in range(world):
+        assert rel_fro(got[f"output_f{v}"], ref["output_f"][v]) < 2e-5
+        assert rel_fro(got[f"output_g{v}"], ref["output_g"][v]) < 2e-5
+        assert rel_fro(got[f"output_s{v}"], ref["output_s"][v]) < 1e-4
