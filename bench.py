@@ -76,7 +76,8 @@ def pass_roofline(make_engine, steps: int, warmup: int) -> dict:
     pass_ms = (t["xg_ms_total"] + t["xtf_ms_total"]) / max(launches, 1)
     bytes_per_launch = (t["xg_bytes"] * t["xg_launches"] + t["xtf_bytes"] * t["xtf_launches"]) / max(launches, 1)
     achieved = bytes_per_launch / (pass_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "pass_kernel<NT,NW,UNROLL,IS_XG,MODE_A> (X.G and Xt.F streaming passes, same pass_body)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+    roofline = {"bound": "hbm", "kernel": "pass_kernel<NT,NW,UNROLL,IS_XG,MODE_A,SPLIT> (X.G and Xt.F streaming passes: pass_body at k <= 16, "
+                                          "pass_body_wide -- three bf16 pieces on the K = 32 MFMA -- above)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "avg_launch_us": round(pass_ms * 1e3, 3), "launches": int(launches),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -89,8 +90,9 @@ def pass_roofline(make_engine, steps: int, warmup: int) -> dict:
     if os.path.exists(traffic_file):
         try:
             t = json.load(open(traffic_file))
-            roofline["traffic"] = t.get("atb_pass_kernel_bytes_per_launch")
-            roofline["traffic_source"] = "static: profiles/traffic.json (" + str(t.get("source", "PMC session")) + ")"
+            if abs(float(t.get("algorithmic_bytes_per_launch", 0.0)) - bytes_per_launch) < 1.0:      # same workload only
+                roofline["traffic"] = t.get("atb_pass_kernel_bytes_per_launch")
+                roofline["traffic_source"] = "static: profiles/traffic.json (" + str(t.get("source", "PMC session")) + ")"
         except Exception:
             pass
     return roofline
@@ -168,6 +170,12 @@ def run_single(args) -> dict:
     }
 
 
+def _all_gather_ints(dist, value: int, world: int):
+    out = [None] * world
+    dist.all_gather_object(out, int(value))
+    return out
+
+
 def run_sharded(args) -> dict:
     import torch
     import torch.distributed as dist
@@ -192,13 +200,23 @@ def run_sharded(args) -> dict:
     else:
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     n_views = world
-    n, m, k = 10000, 2000, 16
+    # BASELINE.json configs[2..4]: c3 on 2 GPUs, c4 on 4, c5 on 8 (one view per GPU); any other N -- or
+    # RESNMTF_BENCH_SAME_SHAPE=1 -- N phi-coupled c2-shaped views (per-GPU work as at N = 1)
+    table = {2: ("c3", [(10000, 2000), (10000, 1500)], 16, dict(phi=200.0)),
+             4: ("c4", [(20000, 4000)] * 4, 32, dict(phi=200.0, psi=200.0)),
+             8: ("c5", [(50000, 8000)] * 8, 64, dict(phi=200.0, xi=200.0, psi=200.0))}
+    if world in table and os.environ.get("RESNMTF_BENCH_SAME_SHAPE") != "1":
+        cfg_name, shapes, k, coupling = table[world]
+    else:
+        cfg_name, shapes, k, coupling = f"{world} x c2", [(10000, 2000)] * world, 16, dict(phi=200.0)
+    n, m = shapes[rank]
     # every rank builds only the view it owns (same seeds as synth.make_problem) + all initial factors
-    prob = sharded.local_problem(n_views, (n, m), k, phi=200.0, owned=[rank])
+    prob = sharded.local_problem(n_views, shapes, k, owned=[rank], **coupling)
     drv = sharded.ShardedSweep(prob, owner_of=list(range(n_views)), rank=rank, world=world, device_index=local_rank,
                                replicate_f=("force" if os.environ.get("RESNMTF_FORCE_REPLICATE") == "1" else
                                             os.environ.get("RESNMTF_NO_REPLICATE") != "1"),
                                allgather_blocks=(os.environ.get("RESNMTF_NO_ALLGATHER") != "1"),
+                               **({"replicate_gs": False} if os.environ.get("RESNMTF_NO_REPLICATE_GS") == "1" else {}),
                                **({"serial_exchange": os.environ["RESNMTF_SERIAL_EXCHANGE"] == "1"}
                                   if "RESNMTF_SERIAL_EXCHANGE" in os.environ else {}))
     if os.environ.get("RESNMTF_FORCE_BCAST") == "1":      # rehearsal: issue the F broadcast even with one rank
@@ -218,6 +236,8 @@ def run_sharded(args) -> dict:
     errs = drv.mean_errors()
     replicated = any(drv.replicated)
     allgather = drv.allgather_layout
+    replicated_gs = drv.replicate_gs
+    n_devices = len({int(d) for d in _all_gather_ints(dist, local_rank, world)})
     drv.close()
     roofline = None
     if rank == 0:      # the same streaming passes (rank 0's own view, same shape) timed per launch while the others wait
@@ -232,6 +252,13 @@ def run_sharded(args) -> dict:
         try:
             roofline = pass_roofline(make_engine, min(args.steps, 200), args.warmup)
             roofline["note"] = "rank 0's view alone (uncoupled), after the timed region"
+            e1, _ = make_engine()
+            e1.run(min(args.steps, 50)); e1.run(3)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            e1.run(min(args.steps, 50))
+            torch.cuda.synchronize()
+            roofline["single_view_updates_per_s"] = round(min(args.steps, 50) / (time.perf_counter() - t1), 2)
+            e1.close()
         except Exception as exc:      # never lose the bench line to the extra leg
             roofline = None
             print(f"[bench] roofline leg failed: {exc}", file=sys.stderr)
@@ -243,12 +270,18 @@ def run_sharded(args) -> dict:
         "metric": METRIC, "value": round(args.steps * n_views / dt, 2), "unit": "view-updates/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{n_views} phi-coupled views 10000x2000 (all rows shared, phi=200), k=16, one view per GPU, "
-                               + (("F chain replicated on every rank (its inputs: one RCCL all-gather per sweep), " if allgather else
-                                   "F chain replicated on every rank (its inputs broadcast once per sweep over RCCL), ")
-                                  if replicated else "F exchanged by ordered RCCL broadcasts, ") + "Gauss-Seidel order kept exactly",
-                   "n_views": n_views, "rows": n, "cols": m, "k": k,
-                   "final_error": float(errs[-1]) if len(errs) else None},
+        "config": {"workload": f"{cfg_name}: {n_views} views " + ",".join(f"{a}x{b}" for a, b in sorted(set(shapes), reverse=True))
+                               + f", k={k}, " + "+".join(f"{key}={val:g}" for key, val in coupling.items())
+                               + " (all rows / columns of coupled views shared), one view per GPU, Gauss-Seidel order kept exactly; "
+                               + ("F, G and S chains replicated on every rank, three block all-gathers per sweep" if replicated_gs else
+                                  ("F chain replicated on every rank (its inputs: one all-gather per sweep)" if allgather else
+                                   "F chain replicated on every rank (its inputs broadcast once per sweep)") if replicated else
+                                  "F exchanged by ordered broadcasts"),
+                   "n_views": n_views, "shapes": [list(sh) for sh in shapes], "k": k,
+                   "backend": ("rccl" if backend == "nccl" else backend), "world_size": world, "distinct_devices": n_devices,
+                   "final_error": float(errs[-1]) if len(errs) else None,
+                   "scaling_note": "BASELINE.json prescribes a different workload per GPU count (c3 / c4 / c5): compare value / n_gpus "
+                                   "with the one-view rate of the same shape (roofline.single_view_updates_per_s), not across N"},
         "roofline": roofline, "cpu_baseline": None,
     }
 

@@ -190,20 +190,21 @@ def make_hip_engine(prob: Problem, owned: Sequence[bool], device_index: int, str
 
 def local_problem(n_views: int, shape, k: int, phi: float = 0.0, xi: float = 0.0, psi: float = 0.0,
                   owned: Optional[Sequence[int]] = None) -> Problem:
-    """``synth.make_problem`` for equal-shaped views, generating the (large) data matrix only for the
-    views in ``owned``; the (small) initial factors of every view are generated everywhere, with
-    the same seeds as ``synth.make_problem`` (1000+v data, 2000+v factors)."""
-    n, m = shape
+    """``synth.make_problem`` generating the (large) data matrix only for the views in ``owned``; the (small) initial
+    factors of every view are generated everywhere, with the same seeds as ``synth.make_problem`` (1000+v data,
+    2000+v factors).  ``shape`` = one (n, m) for all views or a list of them (phi-coupled views share n, psi-coupled
+    views share m: the reference's auto-naming semantics, ``R/utils.r:482-491``)."""
+    shapes = [tuple(shape)] * n_views if isinstance(shape[0], (int, np.integer)) else [tuple(sh) for sh in shape]
     owned = list(range(n_views)) if owned is None else list(owned)
     data, f0, s0, g0 = [], [], [], []
-    for v in range(n_views):
+    for v, (n, m) in enumerate(shapes):
         data.append(planted_view(n, m, k, 1000 + v) if v in owned else None)
         f, s, g = random_init(n, m, k, 2000 + v)
         f0.append(f); s0.append(s); g0.append(g)
     off = 1.0 - np.eye(n_views)
-    prob = Problem(data, f0, s0, g0, phi * off, xi * off, psi * off, k, f"{n_views} views {n}x{m}")
+    prob = Problem(data, f0, s0, g0, phi * off, xi * off, psi * off, k, f"{n_views} views " + ",".join(f"{n}x{m}" for n, m in shapes))
     rn, cn, rb, cb = [], [], 1, 1
-    for v in range(n_views):
+    for v, (n, m) in enumerate(shapes):
         if phi != 0.0:
             rn.append([f"row_{t}" for t in range(1, n + 1)])
         else:
@@ -213,7 +214,7 @@ def local_problem(n_views: int, shape, k: int, phi: float = 0.0, xi: float = 0.0
         else:
             cn.append([f"col_{t}" for t in range(cb, cb + m)]); cb += m
     prob.row_names, prob.col_names = rn, cn
-    prob.extras["shapes"] = [(n, m)] * n_views
+    prob.extras["shapes"] = shapes
     return prob
 
 

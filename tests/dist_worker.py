@@ -264,12 +264,12 @@ def build_problem_one_view_per_rank(world=2, identity=False, xi=0.4):
     return prob
 
 
-def build_problem_gs(world):
+def build_problem_gs(world, k=5):
     """One view per rank, phi + psi + xi all coupling across ranks, rows AND columns shared in part and at different
     positions, a different weight per pair (tests/helpers.py coupled_problem): the replicated-chains layout."""
     from helpers import coupled_problem
     shapes = [(96 + 8 * v, 72 - 8 * (v % 2)) for v in range(world)]
-    prob = coupled_problem(shapes, 5, seed=31 + world, phi_w=1.5, psi_w=1.0, xi_w=0.4)
+    prob = coupled_problem(shapes, k, seed=31 + world, phi_w=1.5, psi_w=1.0, xi_w=0.4)
     prob.extras["shapes"] = shapes
     return prob
 
@@ -282,6 +282,7 @@ def main():
     ap.add_argument("--mode", choices=["cpu", "cpu_gs", "gpu", "gpu_gs", "gpu_norep", "gpu_allgather", "gpu_chain", "gpu_chain_off", "gpu_graph1"], required=True)
     ap.add_argument("--sweeps", type=int, default=12)
     ap.add_argument("--xi", type=float, default=0.4)
+    ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -311,7 +312,7 @@ def main():
     dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
     one_per_rank = a.mode in ("gpu_allgather", "gpu_chain", "gpu_chain_off")
     gs = a.mode in ("cpu_gs", "gpu_gs")
-    prob = (build_problem_gs(a.world) if gs else
+    prob = (build_problem_gs(a.world, a.k) if gs else
             build_problem_one_view_per_rank(a.world, identity=a.mode != "gpu_allgather", xi=a.xi) if one_per_rank else build_problem())
     n_v = len(prob.init_f)
     owner_of = [v % a.world for v in range(n_v)]

@@ -23,13 +23,13 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch(mode, tmp_path, world=2, sweeps=12, timeout=600, xi=0.4):
+def launch(mode, tmp_path, world=2, sweeps=12, timeout=600, xi=0.4, k=5):
     port = free_port()
     out = str(tmp_path / f"sharded_{mode}.npz")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "--rank", str(r),
                                "--world", str(world), "--port", str(port), "--mode", mode, "--sweeps", str(sweeps),
-                               "--xi", str(xi), "--out", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                               "--xi", str(xi), "--k", str(k), "--out", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(world)]
     logs = []
     for p in procs:
@@ -225,11 +225,11 @@ def test_f_chain_eight_view_instantiation_one_process(views):
         assert np.array_equal(out[False][v], out[True][v]), f"view {v}"
 
 
-def oracle_reference_gs(world, sweeps=12):
+def oracle_reference_gs(world, sweeps=12, k=5):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dist_worker
     from oracle import resnmtf_oracle as O
-    prob = dist_worker.build_problem_gs(world)
+    prob = dist_worker.build_problem_gs(world, k)
     return O.res_nmtf_inner(prob.data, prob.init_f, prob.init_s, prob.init_g, prob.phi, prob.xi, prob.psi,
                             row_names=prob.row_names, col_names=prob.col_names, n_iters=sweeps)
 
@@ -251,13 +251,14 @@ def test_replicated_chains_schedule_matches_oracle_gloo_cpu(tmp_path, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3, 4])
-def test_sharded_hip_replicated_g_and_s_chains(tmp_path, world):
+@pytest.mark.parametrize("world,k", [(2, 5), (3, 5), (4, 5), (2, 24), (3, 40), (2, 64)])
+def test_sharded_hip_replicated_g_and_s_chains(tmp_path, world, k):
     """The same layout with the real HIP engine (ranks share the one GPU of the box, gloo): results against the oracle,
-    and every rank's copy of every F, G and S bitwise the owner's."""
-    got = launch("gpu_gs", tmp_path, world=world)
+    and every rank's copy of every F, G and S bitwise the owner's.  k <= 16: hand-off mode A; k = 24 / 40 / 64: mode B
+    (the k x k job of the last-arriving aux workgroup publishes the S block) and the wide bf16-piece passes."""
+    got = launch("gpu_gs", tmp_path, world=world, k=k)
     assert bool(got["mirrors_ok"])
-    ref = oracle_reference_gs(world)
+    ref = oracle_reference_gs(world, k=k)
     np.testing.assert_allclose(got["all_error"], ref["All_Error"], atol=2e-5, rtol=1e-4)
     for v in range(world):
         assert rel_fro(got[f"output_f{v}"], ref["output_f"][v]) < 2e-5
