@@ -36,6 +36,7 @@ for name, phase, base in (("F update", _lib.PHASE_F, 0), ("G update", _lib.PHASE
     if phase == _lib.PHASE_G:
         e.phase(0, _lib.PHASE_F, 3); e.synchronize()
     assert lib.resnmtf_debug_set_stamp_buffer(C.c_void_p(buf.data_ptr())) == 0
+    assert lib.resnmtf_debug_set_stamp_select(2) == 0      # only the update kernels stamp
     e.phase(0, phase, 3); e.synchronize()
     lib.resnmtf_debug_set_stamp_buffer(None)
     t = buf.cpu().numpy().astype(np.int64)[:, base:base + 8]
