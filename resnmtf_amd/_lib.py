@@ -87,11 +87,36 @@ SIGNATURES = {
 _lib = None
 
 
+def _pin_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own ``libamdhip64.so`` (+ HSA runtime); this library is
+    linked against the system's.  Whichever is loaded first serves both (same SONAME) -- and if it is the system's,
+    a later ``import torch`` finds no device ("No HIP GPUs are available": its own HSA runtime comes up beside a foreign
+    HIP).  So when torch is installed but not yet imported, its copy is loaded here first; without torch (an R process
+    calling the C-ABI) the system's runtime is used as linked."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load() -> C.CDLL:
     """Load the in-tree HIP library; raises ImportError loudly when it has not been built."""
     global _lib
     if _lib is not None:
         return _lib
+    _pin_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -m resnmtf_amd.build` "

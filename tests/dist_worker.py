@@ -279,7 +279,7 @@ def main():
     ap.add_argument("--rank", type=int, required=True)
     ap.add_argument("--world", type=int, required=True)
     ap.add_argument("--port", type=int, required=True)
-    ap.add_argument("--mode", choices=["cpu", "cpu_gs", "gpu", "gpu_gs", "gpu_norep", "gpu_allgather", "gpu_chain", "gpu_chain_off", "gpu_graph1"], required=True)
+    ap.add_argument("--mode", choices=["cpu", "cpu_gs", "gpu", "gpu_gs", "gpu_norep", "gpu_allgather", "gpu_chain", "gpu_chain_off", "gpu_graph1", "gpu_gs_rccl1"], required=True)
     ap.add_argument("--sweeps", type=int, default=12)
     ap.add_argument("--xi", type=float, default=0.4)
     ap.add_argument("--k", type=int, default=5)
@@ -307,6 +307,24 @@ def main():
         same = np.array_equal(outs[0][0], outs[1][0]) and all(
             np.array_equal(x, y) for key in outs[0][1] for x, y in zip(outs[0][1][key], outs[1][1][key]))
         np.savez(a.out, same=np.array(same), all_error=outs[1][0])
+        dist.destroy_process_group()
+        return
+    if a.mode == "gpu_gs_rccl1":        # one rank on RCCL: the replicated-chains layout with the in-place all-gathers over the arenas
+        import torch
+        from helpers import rel_fro, run_oracle
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        prob = sharded.local_problem(1, (512, 192), a.k, owned=[0])
+        drv = sharded.ShardedSweep(prob, [0], 0, 1, device_index=0, replicate_f="force", replicate_gs=True)
+        assert drv.replicate_gs
+        drv.run(a.sweeps)
+        torch.cuda.synchronize()
+        errs = drv.mean_errors(); res = drv.gather_results(0)
+        drv.close()
+        ref = run_oracle(prob, n_iters=a.sweeps)
+        ok = (np.allclose(errs, ref["All_Error"], atol=2e-5) and rel_fro(res["output_f"][0], ref["output_f"][0]) < 2e-5 and
+              rel_fro(res["output_g"][0], ref["output_g"][0]) < 2e-5 and rel_fro(res["output_s"][0], ref["output_s"][0]) < 1e-4)
+        np.savez(a.out, same=np.array(ok), all_error=errs)
         dist.destroy_process_group()
         return
     dist.init_process_group("gloo", rank=a.rank, world_size=a.world)

@@ -68,3 +68,14 @@ def test_device_copies_check_shapes():
     np.testing.assert_array_equal(c.get_view(0), a.get_view(0))
     for e in (a, b, c):
         e.close()
+
+
+@pytest.mark.gpu
+def test_torch_imported_after_the_library_still_finds_the_gpu():
+    """PyTorch wheels bundle their own HIP runtime; the library is linked against the system's.  Loading the library first
+    used to leave a later `import torch` without a device ("No HIP GPUs are available"): `_lib._pin_hip_runtime` loads
+    torch's copy first when torch is installed.  Fresh process: library, five sweeps, THEN torch."""
+    import os, subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "load_order_worker.py")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "torch after library: ok True" in out.stdout, out.stdout + out.stderr

@@ -264,3 +264,13 @@ def test_sharded_hip_replicated_g_and_s_chains(tmp_path, world, k):
         assert rel_fro(got[f"output_f{v}"], ref["output_f"][v]) < 2e-5
         assert rel_fro(got[f"output_g{v}"], ref["output_g"][v]) < 2e-5
         assert rel_fro(got[f"output_s{v}"], ref["output_s"][v]) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [7, 40])
+def test_replicated_chains_one_rank_on_rccl(tmp_path, k):
+    """The replicated-chains layout with RCCL as the backend (one rank: RCCL refuses two ranks on one GPU): the in-place
+    all_gather_into_tensor calls over the library's F / G / S block arenas, the block phases in between, results against
+    the oracle."""
+    got = launch("gpu_gs_rccl1", tmp_path, world=1, k=k)
+    assert bool(got["same"])
