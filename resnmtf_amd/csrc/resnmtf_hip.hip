@@ -630,28 +630,34 @@ void size_aux(int rows_pad, int nw, int max_splits, int* nsplit, int* rps);
 //   * CUs that only ran an aux workgroup idle for the rest of a one-round launch.
 // Fewer splits mean less slab traffic (2 KP / rows of the X bytes per split) and fewer per-workgroup prologues.
 struct WidePlan { int tw = 8, nsplit = 1, rps = 64, nsaux = 1, rpsaux = 64; double makespan = 1e300; };
-// Workgroups are dealt round-robin to the 8 XCDs whatever their load (MI355X_MICROARCH.md, Workgroup dispatch): every XCD
-// serves ITS share of the grid with ITS 32 CUs, so the model is one XCD -- the one that also got the k x k job.
-double wide_makespan(int wgs, double d, int n_cu, int aux_wgs, double t_aux, double t_kk) {
-  const int cus = std::max(1, n_cu / 8), my_wgs = ceil_div(wgs, 8), my_aux = std::min(cus, ceil_div(aux_wgs, 8));
-  std::vector<double> free_at((size_t)cus, 0.0);
-  for (int c = 0; c < my_aux; ++c) free_at[(size_t)c] = (c == 0) ? t_aux + t_kk : t_aux;
-  double end = 0.0;
-  for (int w = 0; w < my_wgs; ++w) {
+// Workgroups are dealt round-robin to the 8 XCDs whatever their load (MI355X_MICROARCH.md, Workgroup dispatch): XCD x
+// serves the workgroups i = x (mod 8) of the grid, in order, with ITS CUs -- a workgroup starts on the CU of its XCD that
+// becomes free first.  Grid order: the aux workgroups (t_aux each; the k x k job keeps the CU of the last one t_kk longer),
+// then the main workgroups, split-major; all splits have d_long except the last (d_last).
+double wide_makespan(int ntg, int nsplit, double d_long, double d_last, int n_cu, int aux_wgs, double t_aux, double t_kk) {
+  const int cus = std::max(1, n_cu / 8);
+  std::vector<std::vector<double>> free_at(8, std::vector<double>((size_t)cus, 0.0));
+  auto place = [&](int index, double d) {
+    std::vector<double>& f = free_at[(size_t)(index & 7)];
     size_t cu = 0;
-    for (size_t c = 1; c < free_at.size(); ++c)
-      if (free_at[c] < free_at[cu]) cu = c;
-    free_at[cu] += d;
-    end = std::max(end, free_at[cu]);
-  }
+    for (size_t c = 1; c < f.size(); ++c)
+      if (f[c] < f[cu]) cu = c;
+    f[cu] += d;
+    return f[cu];
+  };
+  double end = 0.0;
+  for (int i = 0; i < aux_wgs; ++i) end = std::max(end, place(i, i == aux_wgs - 1 ? t_aux + t_kk : t_aux));
+  for (int s = 0; s < nsplit; ++s)
+    for (int g = 0; g < ntg; ++g) end = std::max(end, place(aux_wgs + s * ntg + g, s == nsplit - 1 ? d_last : d_long));
   // (the estimate of the main tiles is pessimistic for views that partly fit the Infinity Cache: keep the aux + k x k
   // path well inside it)
   return std::max(end, aux_wgs > 0 ? 1.5 * (t_aux + t_kk) : 0.0);
 }
 WidePlan plan_wide(int ntiles, int rows_pad, int KP, int kinds /* aux products, 0 = hand-off mode A */, int n_cu, int force_ns, int nw) {
   const double t_pass = 4.0 * ntiles * 64.0 * rows_pad / 5.0e6;          // us for the X bytes at 5 TB/s
-  const double t_kk = 12.0 + 130.0 * (KP / 64.0) * (KP / 64.0) * (KP / 64.0);
+  const double t_kk = 12.0 + 50.0 * (KP / 64.0) * (KP / 64.0) * (KP / 64.0);      // tools/stamps.py: 53-63 us at k = 64, 17-18 at k = 32
   WidePlan best;
+  double best_aux_time = 1e300;
   int last_na = -1;
   for (int want : {1, 2, 3, 4, 5, 6, 8, 10, 12, 16}) {
     int na = 1, ra = 64;
@@ -665,14 +671,28 @@ WidePlan plan_wide(int ntiles, int rows_pad, int KP, int kinds /* aux products, 
       const int trip = 32 * (8 / tw), ntg = ceil_div(ntiles, tw);
       for (int ns = 1; ns <= 16; ++ns) {
         if (force_ns > 0 && ns != force_ns) continue;
-        const int r = round_up(ceil_div(rows_pad, ns), trip);
-        const int ns_real = ceil_div(rows_pad, r);
-        if (ns_real != ns && force_ns <= 0) continue;                     // (a shorter list of splits is scored under its own count)
-        const int wgs = ntg * ns_real;
-        const double work = t_pass * n_cu * (1.0 + ns_real * 2.0 * KP / rows_pad) * (tw == 8 ? 1.0 : 1.03);   // CU us
-        const double d = work / wgs + 4.0;
-        const double ms = wide_makespan(wgs, d, n_cu, aux_wgs, t_aux, kinds > 0 ? t_kk : t_kk + 10.0);
-        if (ms < best.makespan) { best.makespan = ms; best.tw = tw; best.nsplit = ns_real; best.rps = r; best.nsaux = na; best.rpsaux = ra; }
+        // equal splits, or a SHORT last split: its workgroups are the last of the grid and start on the CUs the aux
+        // workgroups (and the k x k job) free -- the launch then ends with every CU busy instead of leaving those idle
+        for (double last_share : {1.0, 0.85, 0.7, 0.55, 0.4}) {
+          // (a short last split is there to fill the CUs the aux workgroups free: about as many workgroups as those)
+          if (last_share < 1.0 && (ns < 2 || force_ns > 0 || ntg > aux_wgs + aux_wgs / 2)) continue;
+          const int r = round_up((int)std::ceil(rows_pad / (ns - 1 + last_share)), trip);
+          const int ns_real = ceil_div(rows_pad, r);
+          if (ns_real != ns && force_ns <= 0) continue;                   // (a shorter list of splits is scored under its own count)
+          const int r_last = rows_pad - (ns_real - 1) * r;
+          const double per_row = t_pass * n_cu * (1.0 + ns_real * 2.0 * KP / rows_pad) * (tw == 8 ? 1.0 : 1.03) / ((double)ntg * rows_pad);   // CU us per row of a workgroup
+          const double ms = wide_makespan(ntg, ns_real, per_row * r + 4.0, per_row * r_last + 4.0, n_cu, aux_wgs, t_aux,
+                                          kinds > 0 ? t_kk : t_kk + 10.0);
+          // ties (within 1 %) go to the plan whose aux workgroups and k x k job are done first: which aux workgroup arrives
+          // last -- and hosts the job -- is not known, and a main workgroup that has to wait for that CU in a launch without
+          // slack ends it late (c5 X.G with 3 aux workgroups of 180 us: job done at 245 us, last main workgroup 245 -> 395 us
+          // where the others ended at 337)
+          const bool tie = ms < best.makespan * 1.01 && ms >= best.makespan * 0.99;
+          if (tie && t_aux >= best_aux_time) continue;
+          if (!tie && ms >= best.makespan) continue;
+          best_aux_time = t_aux;
+          best.makespan = std::min(ms, best.makespan); best.tw = tw; best.nsplit = ns_real; best.rps = r; best.nsaux = na; best.rpsaux = ra;
+        }
       }
     }
     if (kinds == 0) break;
