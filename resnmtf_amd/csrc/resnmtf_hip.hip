@@ -1968,7 +1968,23 @@ int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, doubl
   }
   HIP_TRY(h, hipGetLastError());
   if (trace) tp[2] = clk::now();
-  if (int rc = sync_both(h)) return rc;
+  if (tol_arg < 0.0 && !h->opt.time_kernels && h->last_owned >= 0) {
+    // fixed-iteration runs: wait for the sweep counter the LAST k x k job mirrors into pinned host memory (errors are
+    // written, and fenced, before it) instead of a stream synchronisation, whose wake-up costs ~10 us of a 0.9 ms run;
+    // the stream may still be draining the last launch's workgroups -- every other entry point synchronises it first.
+    // Bounded: after 20 ms without progress the stream synchronisation below takes over.
+    const int want = base + total;
+    volatile int* counter = &h->ctl_host->sweep;
+    int seen = *counter;
+    auto t_last = clk::now();
+    while (seen != want) {
+      const int now = *counter;
+      if (now != seen) { seen = now; t_last = clk::now(); }
+      else if (std::chrono::duration<double, std::milli>(clk::now() - t_last).count() > 20.0) break;
+    }
+    if (seen != want)
+      if (int rc = sync_both(h)) return rc;
+  } else if (int rc = sync_both(h)) return rc;
   if (trace) tp[3] = clk::now();
   const int done_total = h->ctl_host->sweep - base;
   if (tol_arg < 0.0 && done_total != total) return h->fail(RESNMTF_ERR_HIP, "sweep counter mismatch");
