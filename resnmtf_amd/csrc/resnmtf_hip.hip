@@ -587,7 +587,7 @@ int flush_timing(resnmtf_handle* h) {
 //   * otherwise 16-step workgroups (512 rows; longer for k > 32) that the dispatcher streams through
 //     the slots.
 // Splits are capped at 16, the depth of the consumer's prefetch.
-void size_pass(int NT, int ntiles, int rows_pad, int slots, int max_nw, int force_nw, int force_ns,
+void size_pass(int NT, int ntiles, int rows_pad, int slots, int max_nw, int force_nw, int force_ns, bool fine,
                int* nsplit, int* rps, int* nw) {
   int w = std::min(8, max_nw);
   if (max_nw > 8 && (force_nw == 4 || force_nw == 8 || force_nw == 16)) w = force_nw;
@@ -596,7 +596,11 @@ void size_pass(int NT, int ntiles, int rows_pad, int slots, int max_nw, int forc
   // longer splits -- there the per-workgroup epilogue (tree sum of 64 accumulator registers per lane +
   // slab store) costs as much as several trips (c5 X.G pass: 744 -> 602 us; k <= 32 prefers short splits)
   // k > 16 (pass_body_k32): a workgroup trip is 256 rows, so splits are whole trips where the extent allows
-  const int gran = NT >= 2 ? quantum : 64;
+  // k <= 16, f32 image: a split is any whole number of 4 w-row steps (the ragged last trip is masked), so splits come out
+  // nearly equal -- c2 X^T.F: 15 x 672 rows instead of 14 x 704 + 192.  Measured neutral (16.4 us either way: with 480
+  // workgroups in flight the launch runs at what the memory system delivers, 5.3 TB/s between ramp and drain); kept for
+  // the even timeline.  The 2-byte images step in 16 w rows and keep 64
+  const int gran = NT >= 2 ? quantum : (fine ? 4 * w : 64);
   int r = 2 * quantum;
   if (NT >= 3) {
     const int ns_stream = std::max(1, std::min(16, ceil_div(8 * (slots + 1), std::max(ntiles, 1))));
@@ -900,9 +904,10 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     const int slots_all = o.target_workgroups > 0 ? o.target_workgroups : h->n_cu * pass_blocks_per_cu(vs.NT, nw_guess);
     const int slots_xg = slots_all - (vs.kk_mode == 0 ? 1 : 3 * vs.nsaux_xg);
     const int slots_xtf = slots_all - (vs.kk_mode == 0 ? 1 : 2 * vs.nsaux_xtf);
-    size_pass(vs.NT, vs.n_pad / 64, vs.m_pad, slots_xg, max_pass_waves(vs.NT), o.pass_waves, o.pass_splits_xg,
+    const bool fine = o.x_half == 0;
+    size_pass(vs.NT, vs.n_pad / 64, vs.m_pad, slots_xg, max_pass_waves(vs.NT), o.pass_waves, o.pass_splits_xg, fine,
               &vs.nsplit_xg, &vs.rps_xg, &vs.nw_xg);
-    size_pass(vs.NT, vs.m_pad / 64, vs.n_pad, slots_xtf, max_pass_waves(vs.NT), o.pass_waves, o.pass_splits_xtf,
+    size_pass(vs.NT, vs.m_pad / 64, vs.n_pad, slots_xtf, max_pass_waves(vs.NT), o.pass_waves, o.pass_splits_xtf, fine,
               &vs.nsplit_xtf, &vs.rps_xtf, &vs.nw_xtf);
     if (vs.NT >= 2 && o.bf16_split != 2) {      // k > 16: the wide bf16-piece form
       const WidePlan pg = plan_wide(vs.n_pad / 64, vs.m_pad, vs.KP, vs.kk_mode == 0 ? 0 : 3, slots_all, o.pass_splits_xg, nw_guess);

@@ -78,8 +78,9 @@ for name, base in (("Xt.F", 8), ("X.G", 0)):
     ids = np.nonzero((tall[:, base] > 0) & (tall[:, base + 1] > 0) & (tall[:, base + 2] == 0))[0]
     endt = (tall[ids, base + 1] - t0) / 100.0
     nt = (m + 63) // 64 if name == "Xt.F" else (n + 63) // 64
-    if prob.k > 16:                      # wide form: tile GROUPS of 8 (or 4) tiles
-        nt = (nt + 7) // 8
+    if prob.k > 16:                      # wide form: tile GROUPS of 8 tiles, or of 4 when that does not divide the grid
+        g8 = (nt + 7) // 8
+        nt = g8 if (len(ids) % g8 == 0 and len(ids) // g8 <= 16) else (nt + 3) // 4
     off = ids.min()                      # first main block
     tile, split = (ids - off) % nt, (ids - off) // nt
     print("  mean end by XCD (block % 8):", np.round([endt[ids % 8 == x].mean() for x in range(8)], 1))
