@@ -96,7 +96,7 @@ typedef struct resnmtf_options {
   int pass_splits_xtf;    /* row splits of the Xt.F pass */
   int pass_lds_pad_kb;    /* extra dynamic LDS per workgroup (caps workgroups per CU) */
   int update_blocks;      /* workgroups per factor-update launch; 0 = default: ~160 (512 above 256 MB of X) in hand-off
-                             mode A, one row group per workgroup up to 1024 in mode B */
+                             mode A, one round of resident workgroups (CUs x 1 at k > 32, x 2 at k = 32) in mode B */
   int no_pitch_pad;       /* 1: do not pad row pitches that are multiples of 4 KiB (A/B testing) */
   int kk_mode;            /* where the k x k products come from: 0 auto, 1 = A (fp64 partials of the update
                              kernels, job in workgroup 0 of the pass launch), 2 = B (MFMA aux tiles, job in

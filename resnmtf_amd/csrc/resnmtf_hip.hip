@@ -923,9 +923,12 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     vs.pp_xtf = vs.NT == 1 && vs.nw_xtf == 8 && (vs.m_pad / 64) * vs.nsplit_xtf > slots_xtf;
     const int RG = update_threads(vs.KP) / vs.KP;
     // update workgroups: mode A ~160 (few partials for the k x k job, two prefetched row groups each
-    // at c2 -- tools/tune_c2.py); mode B one row group per workgroup up to 1024 workgroups (a single
-    // memory round trip each)
-    const int nblk_target = o.update_blocks > 0 ? o.update_blocks : (vs.kk_mode == 0 ? (xbytes <= ((size_t)256 << 20) ? 160 : 512) : 1024);
+    // at c2 -- tools/tune_c2.py); mode B (k > 16) ONE round of resident workgroups -- one 1024-thread workgroup per CU
+    // at k > 32 (127 KB of LDS), two 512-thread ones at k = 32: every workgroup first copies the two k x k coefficient
+    // matrices into LDS (64 KB at k = 64, 13 of the 61 us of a c5-sized F update when three rounds of workgroups each
+    // did it: tools/ab_update_blocks.sh, F update 61 -> 43 us at c5, 13.5 -> 11.8 at c4; G 19 -> 14.5 at c5)
+    const int nblk_round = h->n_cu * (update_threads(vs.KP) >= 1024 ? 1 : 2);
+    const int nblk_target = o.update_blocks > 0 ? o.update_blocks : (vs.kk_mode == 0 ? (xbytes <= ((size_t)256 << 20) ? 160 : 512) : nblk_round);
     vs.rpbF = round_up(std::max(RG, ceil_div(vs.n, nblk_target)), RG); vs.nblkF = ceil_div(vs.n, vs.rpbF);
     vs.rpbG = round_up(std::max(RG, ceil_div(vs.m, nblk_target)), RG); vs.nblkG = ceil_div(vs.m, vs.rpbG);
     const size_t kkp = (size_t)vs.KP * vs.KP;

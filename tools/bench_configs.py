@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("configs", nargs="*", default=["c2", "c3", "c4v1", "c5v1"])
 ap.add_argument("--sweeps", type=int, default=100)
 ap.add_argument("--bf16-split", type=int, default=0)
+ap.add_argument("--update-blocks", type=int, default=0)
 a = ap.parse_args()
 SHAPES = {
     "c2": ([(10000, 2000)], 16, {}),
@@ -30,7 +31,7 @@ for name in a.configs:
     gen = time.perf_counter() - t0
     V = len(shapes)
     def mk(**extra):
-        e = Engine([s[0] for s in shapes], [s[1] for s in shapes], [k] * V, bf16_split=a.bf16_split, **extra)
+        e = Engine([s[0] for s in shapes], [s[1] for s in shapes], [k] * V, bf16_split=a.bf16_split, update_blocks=a.update_blocks, **extra)
         for v in range(V):
             e.set_view(v, prob.data[v]); e.set_factors(v, prob.init_f[v], prob.init_s[v], prob.init_g[v])
         e.set_restrictions(prob.phi, prob.xi, prob.psi)
