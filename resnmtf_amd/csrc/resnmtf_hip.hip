@@ -1711,6 +1711,7 @@ static int build_args(resnmtf_handle* h) {
     f.len = vs.n; f.k = vs.k; f.W = vs.F; f.W32 = vs.F32; f.Wk = vs.Fk; f.ld32 = vs.kk_mode == 0 ? vs.KP : 64; f.kpack32 = vs.half ? 1 : 0;
     f.P = vs.Pxg; f.nsplit = vs.nsplit_xg; f.cols_pad = vs.n_pad;
     if (vs.Usum) { f.P = vs.Usum; f.nsplit = 1; }      // replicate_f: the folded slab of the exchange block
+    if (!vs.owned && vs.NT >= 2) { f.W32 = nullptr; f.Wk = nullptr; }   // only this view's passes (on its owner) read them
     f.Ma = vs.Ma_F; f.Md = vs.Md_F; f.lm = vs.lambda; f.T32 = nullptr; f.part = vs.partF;
     f.rows_per_block = vs.rpbF; f.ctl = h->ctl;
     {
@@ -1737,6 +1738,7 @@ static int build_args(resnmtf_handle* h) {
     g.P = vs.Pxtf; g.nsplit = vs.nsplit_xtf; g.cols_pad = vs.m_pad;
     if (vs.Tsum) { g.P = vs.Tsum; g.nsplit = 1; }      // replicate_gs: the folded slab of the exchange block
     g.Ma = vs.Ma_G; g.Md = vs.Md_G; g.lm = vs.mu; g.T32 = vs.T32; g.part = vs.partG;
+    if (!vs.owned && vs.NT >= 2) { g.W32 = nullptr; g.Wk = nullptr; g.T32 = nullptr; }
     g.rows_per_block = vs.rpbG; g.ctl = h->ctl;
     {
       double sigma = 0.0;
