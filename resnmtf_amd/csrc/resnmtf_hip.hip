@@ -253,10 +253,12 @@ hipError_t set_all_attrs() {
   TRY_ATTR(set_smem_attrs<48>()); TRY_ATTR(set_smem_attrs<64>());
   TRY_ATTR((set_pass_attr<1, 4, 8>())); TRY_ATTR((set_pass_attr<1, 8, 8>())); TRY_ATTR((set_pass_attr<1, 8, 4>())); TRY_ATTR((set_pass_attr<1, 16, 8>()));
   TRY_ATTR((set_pass_attr<2, 8, 4>())); TRY_ATTR((set_pass_attr<3, 8, 4>())); TRY_ATTR((set_pass_attr<4, 8, 4>()));
-  TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&s_chain_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-  TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&s_chain_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-  TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&s_chain_kernel<48>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-  TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&s_chain_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+#define S_CHAIN_ATTR(KPV, NVBV) TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&s_chain_kernel<KPV, NVBV>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds))
+  S_CHAIN_ATTR(16, 4); S_CHAIN_ATTR(16, 8); S_CHAIN_ATTR(16, RESNMTF_MAX_COUPLE + 1);
+  S_CHAIN_ATTR(32, 4); S_CHAIN_ATTR(32, 8); S_CHAIN_ATTR(32, RESNMTF_MAX_COUPLE + 1);
+  S_CHAIN_ATTR(48, 4); S_CHAIN_ATTR(48, 8); S_CHAIN_ATTR(48, RESNMTF_MAX_COUPLE + 1);
+  S_CHAIN_ATTR(64, 4); S_CHAIN_ATTR(64, 8); S_CHAIN_ATTR(64, RESNMTF_MAX_COUPLE + 1);
+#undef S_CHAIN_ATTR
 #define CHAIN_ATTR(NVB, PFV) TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&f_chain_kernel<NVB, PFV>), \
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)f_chain_smem_bytes<NVB>()))
   CHAIN_ATTR(2, 1); CHAIN_ATTR(4, 1); CHAIN_ATTR(8, 1); CHAIN_ATTR(2, 4); CHAIN_ATTR(4, 4); CHAIN_ATTR(8, 4);
@@ -477,12 +479,17 @@ int launch_s_chain(resnmtf_handle* h, int sweep) {
   a.err = h->err; a.err_stride = V; a.err_cap = h->err_cap; a.err_host = h->err_host_dev;
   a.ctl = h->ctl; a.ctl_host = h->ctl_host_dev;
   const size_t smem = kk_smem_bytes(v0.KP, 8);
+#define S_CHAIN(KPV) do { \
+    if (V <= 4) hipLaunchKernelGGL((s_chain_kernel<KPV, 4>), dim3(V), dim3(512), smem, h->stream, a); \
+    else if (V <= 8) hipLaunchKernelGGL((s_chain_kernel<KPV, 8>), dim3(V), dim3(512), smem, h->stream, a); \
+    else hipLaunchKernelGGL((s_chain_kernel<KPV, RESNMTF_MAX_COUPLE + 1>), dim3(V), dim3(512), smem, h->stream, a); } while (0)
   switch (v0.NT) {
-    case 1: hipLaunchKernelGGL(s_chain_kernel<16>, dim3(V), dim3(512), smem, h->stream, a); break;
-    case 2: hipLaunchKernelGGL(s_chain_kernel<32>, dim3(V), dim3(512), smem, h->stream, a); break;
-    case 3: hipLaunchKernelGGL(s_chain_kernel<48>, dim3(V), dim3(512), smem, h->stream, a); break;
-    default: hipLaunchKernelGGL(s_chain_kernel<64>, dim3(V), dim3(512), smem, h->stream, a); break;
+    case 1: S_CHAIN(16); break;
+    case 2: S_CHAIN(32); break;
+    case 3: S_CHAIN(48); break;
+    default: S_CHAIN(64); break;
   }
+#undef S_CHAIN
   return RESNMTF_OK;
 }
 void enqueue_phase_g(resnmtf_handle* h, const ViewState& v, double tol, bool checked) {
