@@ -121,6 +121,9 @@ struct resnmtf_handle {
   int n_cu = 256;                     // compute units of the device (multiProcessorCount)
   ChainArgs<8> chain{};               // RESNMTF_PHASE_F_ALL: the F updates of every view in one launch (when eligible)
   int chain_views = 0;                // 0 = not eligible: one launch per view
+  WideChainArgs<8> wchain[2]{};       // k = 32 / 64: the F ([0]) and G ([1]) updates of every view in one launch (wide_chain_kernel)
+  bool wchain_ok[2] = {false, false};
+  int wchain_grid[2] = {0, 0};
   int chain_blocks = 0;
   void* fblk_arena = nullptr;         // replicate_f: the F exchange blocks of all views, in view order
   size_t fblk_arena_bytes = 0;
@@ -259,6 +262,11 @@ hipError_t set_all_attrs() {
   S_CHAIN_ATTR(48, 4); S_CHAIN_ATTR(48, 8); S_CHAIN_ATTR(48, RESNMTF_MAX_COUPLE + 1);
   S_CHAIN_ATTR(64, 4); S_CHAIN_ATTR(64, 8); S_CHAIN_ATTR(64, RESNMTF_MAX_COUPLE + 1);
 #undef S_CHAIN_ATTR
+#define WCHAIN_ATTR(KPV, G, NVBV) TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_chain_kernel<KPV, G, NVBV>), \
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_chain_smem_bytes(KPV)))
+  WCHAIN_ATTR(32, false, 4); WCHAIN_ATTR(32, true, 4); WCHAIN_ATTR(32, false, 8); WCHAIN_ATTR(32, true, 8);
+  WCHAIN_ATTR(64, false, 4); WCHAIN_ATTR(64, true, 4); WCHAIN_ATTR(64, false, 8); WCHAIN_ATTR(64, true, 8);
+#undef WCHAIN_ATTR
 #define CHAIN_ATTR(NVB, PFV) TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&f_chain_kernel<NVB, PFV>), \
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)f_chain_smem_bytes<NVB>()))
   CHAIN_ATTR(2, 1); CHAIN_ATTR(4, 1); CHAIN_ATTR(8, 1); CHAIN_ATTR(2, 4); CHAIN_ATTR(4, 4); CHAIN_ATTR(8, 4);
@@ -415,8 +423,40 @@ void launch_update(resnmtf_handle* h, const ViewState& v, int kind, bool check_d
 #undef LAUNCH_UPD_K
 }
 
+template <int NVB>
+WideChainArgs<NVB> narrow_wchain(const WideChainArgs<8>& c) {
+  WideChainArgs<NVB> a{};
+  a.len = c.len; a.k = c.k; a.n_views = c.n_views; a.ngroups = c.ngroups; a.own = c.own;
+  a.W32 = c.W32; a.Wk = c.Wk; a.T32 = c.T32; a.ld32 = c.ld32; a.ctl = c.ctl; a.check_done = c.check_done; a.restricted = c.restricted;
+  for (int v = 0; v < NVB; ++v) {
+    a.W[v] = c.W[v]; a.U[v] = c.U[v]; a.Ma[v] = c.Ma[v]; a.Md[v] = c.Md[v]; a.lm[v] = c.lm[v];
+    a.sigma[v] = c.sigma[v]; a.n_other[v] = c.n_other[v]; a.cmask[v] = c.cmask[v];
+    for (int w = 0; w < NVB; ++w) a.weight[v][w] = c.weight[v][w];
+  }
+  return a;
+}
+// k = 32 / 64: update_f (g == 0) or update_g (g == 1) of every view in one launch
+void launch_wide_chain(resnmtf_handle* h, int g, bool checked) {
+  WideChainArgs<8>& c = h->wchain[g];
+  c.check_done = checked ? 1 : 0;
+  const int KP = h->views[0].KP;
+  const size_t smem = wide_chain_smem_bytes(KP);
+  const dim3 grid(h->wchain_grid[g]), block(16 * KP);
+#define WCHAIN(KPV, NVBV, ARGS) do { \
+    if (g == 0) hipLaunchKernelGGL((wide_chain_kernel<KPV, false, NVBV>), grid, block, smem, h->stream, ARGS); \
+    else hipLaunchKernelGGL((wide_chain_kernel<KPV, true, NVBV>), grid, block, smem, h->stream, ARGS); } while (0)
+  if (c.n_views <= 4) {
+    WideChainArgs<4> a = narrow_wchain<4>(c);
+    if (KP == 32) WCHAIN(32, 4, a); else WCHAIN(64, 4, a);
+  } else {
+    if (KP == 32) WCHAIN(32, 8, c); else WCHAIN(64, 8, c);
+  }
+#undef WCHAIN
+}
+
 // RESNMTF_PHASE_F_ALL: update_f of every view in view order (one launch when the chain is eligible)
 void enqueue_phase_f_all(resnmtf_handle* h, bool checked = false) {
+  if (h->wchain_ok[0]) { launch_wide_chain(h, 0, checked); return; }
   if (h->chain_views > 0) {
     h->chain.check_done = checked ? 1 : 0;
     const size_t smem = h->chain_views <= 2 ? f_chain_smem_bytes<2>() : h->chain_views <= 4 ? f_chain_smem_bytes<4>() : f_chain_smem_bytes<8>();
@@ -1702,6 +1742,51 @@ static void build_chain(resnmtf_handle* h) {
   h->chain_blocks = v0.nblkF;
 }
 
+// RESNMTF_PHASE_F_ALL / G_ALL in one launch at k = 32 / 64 (wide_chain_kernel): every view holds the inputs of the update
+// here (owned or replica) as ONE folded slab (the exchange blocks of replicate_f / replicate_gs), equal lengths and k,
+// every coupling through identity maps, at most one owned view, at most 8 views.  Otherwise one launch per view.
+static void build_wide_chain(resnmtf_handle* h) {
+  h->wchain_ok[0] = h->wchain_ok[1] = false;
+  const int V = h->V;
+  if (V < 2 || V > 8 || h->opt.no_f_chain) return;
+  const ViewState& v0 = h->views[0];
+  if (v0.KP != 32 && v0.KP != 64) return;
+  for (int g = 0; g < 2; ++g) {
+    WideChainArgs<8>& a = h->wchain[g];
+    a = WideChainArgs<8>{};
+    a.own = -1;
+    bool ok = true;
+    int n_owned = 0;
+    for (int v = 0; v < V && ok; ++v) {
+      const ViewState& vs = h->views[v];
+      const UpdateArgs& u = g == 0 ? vs.argF : vs.argG;
+      if (!vs.owned && !(g == 0 ? vs.f_replica : vs.g_replica)) { ok = false; break; }
+      if (vs.KP != v0.KP || vs.k != v0.k || (g == 0 ? vs.n != v0.n : vs.m != v0.m)) { ok = false; break; }
+      if (u.nsplit != 1 || u.P == nullptr) { ok = false; break; }            // the folded slab of an exchange block
+      for (int c = 0; c < u.n_couple; ++c)
+        if (u.couple[c].map) ok = false;                                     // permuted shared rows: rows of other workgroups
+      if (vs.owned) {
+        if (++n_owned > 1) { ok = false; break; }
+        a.own = v; a.W32 = g == 0 ? vs.F32 : vs.G32; a.Wk = g == 0 ? vs.Fk : vs.Gk; a.T32 = g == 0 ? nullptr : vs.T32; a.ld32 = u.ld32;
+        if (!a.W32 || !a.Wk || (g == 1 && !a.T32)) { ok = false; break; }
+      }
+      a.W[v] = u.W; a.U[v] = u.P; a.Ma[v] = u.Ma; a.Md[v] = u.Md; a.lm[v] = u.lm;
+      a.sigma[v] = u.sigma;
+      a.n_other[v] = (double)(g == 0 ? vs.n : vs.m);
+      if (u.restricted) a.restricted |= 1u << v;
+      for (int c = 0; c < u.n_couple; ++c)
+        for (int w = 0; w < V; ++w)
+          if (u.couple[c].W == (g == 0 ? h->views[w].F : h->views[w].G)) { a.cmask[v] |= 1u << w; a.weight[v][w] = u.couple[c].weight; }
+    }
+    if (!ok) continue;
+    a.len = g == 0 ? v0.n : v0.m; a.k = v0.k; a.n_views = V; a.ngroups = ceil_div(a.len, 32);
+    a.ctl = h->ctl;
+    // persistent workgroups: one per CU at k = 64 (157 KB of LDS), two at k = 32
+    h->wchain_grid[g] = std::min(a.ngroups, h->n_cu * (v0.KP == 32 ? 2 : 1));
+    h->wchain_ok[g] = true;
+  }
+}
+
 // builds the kernel argument blocks (coupling tables included) from the host-side description
 static int build_args(resnmtf_handle* h) {
   const int V = h->V;
@@ -1817,6 +1902,7 @@ static int build_args(resnmtf_handle* h) {
     }
   }
   build_chain(h);
+  build_wide_chain(h);
   return RESNMTF_OK;
 }
 
@@ -1885,6 +1971,7 @@ int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep) {
       break;
     case RESNMTF_PHASE_XTF: launch_pass(h, vs, false, 1, -1.0, false); launch_fold_t(h, vs); break;
     case RESNMTF_PHASE_G_ALL:
+      if (h->wchain_ok[1]) { launch_wide_chain(h, 1, false); break; }
       for (const auto& w : h->views)
         if (w.owned || w.g_replica) launch_update(h, w, 1, false);
       break;

@@ -225,6 +225,60 @@ def test_f_chain_eight_view_instantiation_one_process(views):
         assert np.array_equal(out[False][v], out[True][v]), f"view {v}"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("views,k,n,m", [(3, 24, 700, 200), (6, 32, 333, 161), (4, 64, 1000, 330), (8, 64, 517, 96), (8, 57, 2100, 64)])
+def test_wide_chain_one_process_bitwise(views, k, n, m):
+    """One rank's share of a `views`-way sharded run with replicated F / G / S chains at k > 16, in ONE process: view 0
+    owned, the others replicas whose exchange blocks are copies of view 0's.  The fused launches (wide_chain_kernel, F and
+    G form) against one factor_update_kernel launch per view: every view's F and G bitwise, and the owned view's operand
+    copies too (seen through the next pass: the T and U blocks it produces)."""
+    import torch
+    from resnmtf_amd import _lib, sharded
+    from resnmtf_amd.engine import Engine
+    prob = sharded.local_problem(views, (n, m), k, phi=3.0, xi=2.0, psi=1.5, owned=[0])
+    out = {}
+    for off in (False, True):
+        st = torch.cuda.Stream()
+        eng = Engine([n] * views, [m] * views, [k] * views, owned=[v == 0 for v in range(views)], stream=st.cuda_stream,
+                     replicate_f=True, replicate_gs=True, no_f_chain=off)
+        eng.set_view(0, prob.data[0])
+        for v in range(views):
+            eng.set_factors(v, prob.init_f[v], prob.init_s[v], prob.init_g[v])
+        eng.set_restrictions(prob.phi, prob.xi, prob.psi)
+        ri, ci = np.arange(n, dtype=np.int32), np.arange(m, dtype=np.int32)
+        for v in range(views):
+            for w in range(views):
+                if v != w:
+                    eng.set_shared_rows(v, w, ri, ri)
+                    eng.set_shared_cols(v, w, ci, ci)
+        eng.reserve_sweeps(64)
+        eng.prepare()
+        eng.synchronize()
+        ad = sharded.HipEngineAdapter(eng)
+        res = []
+        steps = (("FBLOCK", (_lib.PHASE_F_ALL, _lib.PHASE_XTF)), ("GBLOCK", (_lib.PHASE_G_ALL, _lib.PHASE_XG)),
+                 ("SBLOCK", (_lib.PHASE_S_ALL,)))
+        for t in range(2):
+            for kind, phases in steps:                 # stand-in for the exchange: every view's block = a copy of view 0's
+                blk0 = ad.factor_tensor(0, kind)
+                for v in range(1, views):
+                    ad.factor_tensor(v, kind).copy_(blk0)
+                torch.cuda.synchronize()
+                for ph in phases:
+                    eng.phase(0, ph, t)
+                eng.synchronize()
+            res.append([ad.factor_tensor(v, "F").cpu().numpy().copy() for v in range(views)])
+            res.append([ad.factor_tensor(v, "G").cpu().numpy().copy() for v in range(views)])
+            res.append([ad.factor_tensor(0, kind).cpu().numpy().copy() for kind in ("FBLOCK", "GBLOCK", "SBLOCK")])
+        out[off] = res
+        ad._views.clear()
+        eng.close()
+    for a, b in zip(out[False], out[True]):
+        for x, y in zip(a, b):
+            assert np.isfinite(x).all() and np.abs(x).max() > 0
+            assert np.array_equal(x, y)
+
+
 def oracle_reference_gs(world, sweeps=12, k=5):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dist_worker
