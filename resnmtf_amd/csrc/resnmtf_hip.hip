@@ -518,11 +518,11 @@ int launch_s_chain(resnmtf_handle* h, int sweep) {
   }
   a.err = h->err; a.err_stride = V; a.err_cap = h->err_cap; a.err_host = h->err_host_dev;
   a.ctl = h->ctl; a.ctl_host = h->ctl_host_dev;
-  const size_t smem = kk_smem_bytes(v0.KP, 8);
+  const size_t smem = kk_smem_bytes(v0.KP, 16);
 #define S_CHAIN(KPV) do { \
-    if (V <= 4) hipLaunchKernelGGL((s_chain_kernel<KPV, 4>), dim3(V), dim3(512), smem, h->stream, a); \
-    else if (V <= 8) hipLaunchKernelGGL((s_chain_kernel<KPV, 8>), dim3(V), dim3(512), smem, h->stream, a); \
-    else hipLaunchKernelGGL((s_chain_kernel<KPV, RESNMTF_MAX_COUPLE + 1>), dim3(V), dim3(512), smem, h->stream, a); } while (0)
+    if (V <= 4) hipLaunchKernelGGL((s_chain_kernel<KPV, 4>), dim3(V), dim3(s_chain_threads(KPV)), smem, h->stream, a); \
+    else if (V <= 8) hipLaunchKernelGGL((s_chain_kernel<KPV, 8>), dim3(V), dim3(s_chain_threads(KPV)), smem, h->stream, a); \
+    else hipLaunchKernelGGL((s_chain_kernel<KPV, RESNMTF_MAX_COUPLE + 1>), dim3(V), dim3(s_chain_threads(KPV)), smem, h->stream, a); } while (0)
   switch (v0.NT) {
     case 1: S_CHAIN(16); break;
     case 2: S_CHAIN(32); break;
