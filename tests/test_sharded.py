@@ -305,11 +305,12 @@ def test_replicated_chains_schedule_matches_oracle_gloo_cpu(tmp_path, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,k", [(2, 5), (3, 5), (4, 5), (2, 24), (3, 40), (2, 64)])
+@pytest.mark.parametrize("world,k", [(2, 5), (3, 5), (4, 5), (2, 24), (4, 32), (3, 40), (2, 64), (3, 57)])
 def test_sharded_hip_replicated_g_and_s_chains(tmp_path, world, k):
     """The same layout with the real HIP engine (ranks share the one GPU of the box, gloo): results against the oracle,
     and every rank's copy of every F, G and S bitwise the owner's.  k <= 16: hand-off mode A; k = 24 / 40 / 64: mode B
-    (the k x k job of the last-arriving aux workgroup publishes the S block) and the wide bf16-piece passes."""
+    (the k x k job of the last-arriving aux workgroup publishes the S block), the wide bf16-piece passes and -- k = 24 / 32 / 57 / 64 --
+    the fused chain launches (wide_chain_kernel; k = 40 has none and takes one launch per view)."""
     got = launch("gpu_gs", tmp_path, world=world, k=k)
     assert bool(got["mirrors_ok"])
     ref = oracle_reference_gs(world, k=k)
