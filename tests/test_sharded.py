@@ -226,6 +226,53 @@ def test_f_chain_eight_view_instantiation_one_process(views):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("views,k,n,m", [(3, 32, 450, 130), (5, 64, 300, 70)])
+def test_wide_chain_f_only_one_process_bitwise(views, k, n, m):
+    """The same for a phi-only layout (replicated F chain, G and S stay with the owner): PHASE_F_ALL through
+    wide_chain_kernel against one launch per view, then the owner's PHASE_G on the result -- F of every view, G and S of
+    the owned one, bitwise."""
+    import torch
+    from resnmtf_amd import _lib, sharded
+    from resnmtf_amd.engine import Engine
+    prob = sharded.local_problem(views, (n, m), k, phi=3.0, owned=[0])
+    out = {}
+    for off in (False, True):
+        st = torch.cuda.Stream()
+        eng = Engine([n] * views, [m] * views, [k] * views, owned=[v == 0 for v in range(views)], stream=st.cuda_stream,
+                     replicate_f=True, no_f_chain=off)
+        eng.set_view(0, prob.data[0])
+        for v in range(views):
+            eng.set_factors(v, prob.init_f[v], prob.init_s[v], prob.init_g[v])
+        eng.set_restrictions(prob.phi, prob.xi, prob.psi)
+        ri = np.arange(n, dtype=np.int32)
+        for v in range(views):
+            for w in range(views):
+                if v != w:
+                    eng.set_shared_rows(v, w, ri, ri)
+                    eng.set_shared_cols(v, w, None, None)
+        eng.reserve_sweeps(64)
+        eng.prepare()
+        eng.synchronize()
+        ad = sharded.HipEngineAdapter(eng)
+        for t in range(3):
+            blk0 = ad.factor_tensor(0, "FBLOCK")
+            for v in range(1, views):
+                ad.factor_tensor(v, "FBLOCK").copy_(blk0)
+            torch.cuda.synchronize()
+            eng.phase(0, _lib.PHASE_F_ALL, t)
+            eng.phase(0, _lib.PHASE_G, t)
+            eng.synchronize()
+        res = [ad.factor_tensor(v, "F").cpu().numpy().copy() for v in range(views)]
+        res += [ad.factor_tensor(0, "G").cpu().numpy().copy(), ad.factor_tensor(0, "S").cpu().numpy().copy()]
+        out[off] = res
+        ad._views.clear()
+        eng.close()
+    for x, y in zip(out[False], out[True]):
+        assert np.isfinite(x).all() and np.abs(x).max() > 0
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("views,k,n,m", [(3, 24, 700, 200), (6, 32, 333, 161), (4, 64, 1000, 330), (8, 64, 517, 96), (8, 57, 2100, 64)])
 def test_wide_chain_one_process_bitwise(views, k, n, m):
     """One rank's share of a `views`-way sharded run with replicated F / G / S chains at k > 16, in ONE process: view 0
