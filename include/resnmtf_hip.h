@@ -51,7 +51,10 @@ enum { RESNMTF_FACTOR_F = 0, RESNMTF_FACTOR_G = 1, RESNMTF_FACTOR_S = 2,
        RESNMTF_FACTOR_GBLOCK_ALL = 6, /* ... of all views, contiguous in view order */
        RESNMTF_FACTOR_SBLOCK = 7, /* replicate_gs: the S update's inputs of view v (fp64: old S | F^T X G | (F^T F S)(G^T G) |
                                      G^T G | F^T F | colSums(G) | colSums(F) | ||X||^2) */
-       RESNMTF_FACTOR_SBLOCK_ALL = 8 /* ... of all views, contiguous in view order (equal k: equal blocks) */ };
+       RESNMTF_FACTOR_SBLOCK_ALL = 8 /* ... of all views, contiguous in view order (equal k: equal blocks).  With equal-shaped
+                                        views the S block of a view sits at the end of its F block instead (the address
+                                        RESNMTF_FACTOR_SBLOCK returns lies inside RESNMTF_FACTOR_FBLOCK's range): gathering
+                                        the F blocks after RESNMTF_PHASE_XG moves both, and this selector is refused */ };
 
 /* phases of one view's update inside a sweep (R/update_steps.r:282-314) */
 enum {
@@ -132,7 +135,8 @@ typedef struct resnmtf_options {
                              RESNMTF_FACTOR_GBLOCK) and of its S update (old S, F^T X G, (F^T F S)(G^T G), the two Gram
                              matrices, column sums, ||X||^2: RESNMTF_FACTOR_SBLOCK), runs RESNMTF_PHASE_G_ALL /
                              RESNMTF_PHASE_S_ALL for all views itself and only streams its own X (RESNMTF_PHASE_XTF /
-                             RESNMTF_PHASE_XG): three all-gathers per sweep (T blocks, S blocks, U blocks) instead of
+                             RESNMTF_PHASE_XG): two all-gathers per sweep (T blocks; U blocks with the S blocks inside --
+                             three, S blocks on their own, when the views' F blocks differ in size) instead of
                              2 V ordered broadcasts, and the two streaming passes of all ranks run at the same time
                              (psi / xi coupling; R/update_steps.r:195-204, :231-237).  Needs equal k in all views. */
 } resnmtf_options;

@@ -129,6 +129,8 @@ struct resnmtf_handle {
   size_t fblk_arena_bytes = 0;
   void* gblk_arena = nullptr; size_t gblk_arena_bytes = 0;     // replicate_gs: the G / S exchange blocks of all views
   double* sblk_arena = nullptr; size_t sblk_stride = 0;        //   (S blocks: sblk_stride doubles each)
+  bool sblk_embedded = false;         // the S block of a view sits at the end of its F block (equal-shaped views): they travel together
+  double* sblk_base = nullptr; size_t sblk_step = 0;           // S block of view v = sblk_base + v * sblk_step (doubles)
   // pass timing (eager mode)
   std::vector<hipEvent_t> ev;         // pairs
   std::vector<int> ev_kind;           // 0 = xg, 1 = xtf per pair
@@ -501,7 +503,7 @@ int launch_s_chain(resnmtf_handle* h, int sweep) {
   const int V = h->V;
   const ViewState& v0 = h->views[0];
   a.k = v0.k; a.n_views = V; a.sweep = sweep;
-  a.sblocks = h->sblk_arena; a.sblock_stride = h->sblk_stride;
+  a.sblocks = h->sblk_base; a.sblock_stride = h->sblk_step;
   double sum_xi = 0.0;
   for (double x : h->xi) sum_xi += x;
   a.restricted = sum_xi != 0.0 ? 1 : 0;
@@ -905,8 +907,22 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
   auto fblk_size = [&](const ViewState& vs) {
     return (fblk_usum_bytes(vs) + (2 * (size_t)vs.k * vs.k + (size_t)vs.k) * sizeof(double) + 255) / 256 * 256;
   };
+  // replicate_gs, equal-shaped F blocks: the S block of a view (k x k inputs of the S rule, written by the same pass launch
+  // that produces U) is appended to its F block, so that ONE all-gather after the X.G pass moves both -- two collectives per
+  // sweep between dependent steps instead of three
+  size_t sblk_tail_bytes = 0;
+  if (o.replicate_f && o.replicate_gs) {
+    bool equal = true;
+    for (const auto& vs : h->views) equal = equal && fblk_size(vs) == fblk_size(h->views[0]) && vs.k == h->views[0].k;
+    if (equal) {
+      const size_t kk0 = (size_t)h->views[0].k * h->views[0].k;
+      h->sblk_stride = (5 * kk0 + 2 * (size_t)h->views[0].k + 1 + 31) / 32 * 32;
+      sblk_tail_bytes = (h->sblk_stride * sizeof(double) + 255) / 256 * 256;
+      h->sblk_embedded = true;
+    }
+  }
   if (o.replicate_f) {
-    for (const auto& vs : h->views) h->fblk_arena_bytes += fblk_size(vs);
+    for (const auto& vs : h->views) h->fblk_arena_bytes += fblk_size(vs) + sblk_tail_bytes;
     if ((e = hipMalloc(&h->fblk_arena, h->fblk_arena_bytes)) != hipSuccess) return bail(e, "hipMalloc F exchange blocks");
     if ((e = hipMemset(h->fblk_arena, 0, h->fblk_arena_bytes)) != hipSuccess) return bail(e, "hipMemset F exchange blocks");
   }
@@ -921,9 +937,12 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     for (const auto& vs : h->views) h->gblk_arena_bytes += gblk_size(vs);
     if ((e = hipMalloc(&h->gblk_arena, h->gblk_arena_bytes)) != hipSuccess) return bail(e, "hipMalloc G exchange blocks");
     if ((e = hipMemset(h->gblk_arena, 0, h->gblk_arena_bytes)) != hipSuccess) return bail(e, "hipMemset G exchange blocks");
-    const size_t kk0 = (size_t)h->views[0].k * h->views[0].k;
-    h->sblk_stride = (5 * kk0 + 2 * (size_t)h->views[0].k + 1 + 31) / 32 * 32;
-    if ((e = dev_alloc_zero(&h->sblk_arena, h->sblk_stride * n_views)) != hipSuccess) return bail(e, "hipMalloc S exchange blocks");
+    if (!h->sblk_embedded) {
+      const size_t kk0 = (size_t)h->views[0].k * h->views[0].k;
+      h->sblk_stride = (5 * kk0 + 2 * (size_t)h->views[0].k + 1 + 31) / 32 * 32;
+      if ((e = dev_alloc_zero(&h->sblk_arena, h->sblk_stride * n_views)) != hipSuccess) return bail(e, "hipMalloc S exchange blocks");
+      h->sblk_base = h->sblk_arena; h->sblk_step = h->sblk_stride;
+    }
   }
   size_t fblk_off = 0, gblk_off = 0;
   for (int v = 0; v < n_views; ++v) {
@@ -983,8 +1002,12 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     // (the sharded driver broadcasts it from the owner and runs the F update of coupled views everywhere)
     const size_t pxg_floats = (size_t)vs.nsplit_xg * vs.n_pad * vs.KP;
     if (o.replicate_f) {
-      vs.fblk_bytes = fblk_size(vs);
+      vs.fblk_bytes = fblk_size(vs) + sblk_tail_bytes;
       char* base = static_cast<char*>(h->fblk_arena) + fblk_off;
+      if (h->sblk_embedded) {
+        vs.sblk = reinterpret_cast<double*>(base + fblk_size(vs));
+        if (v == 0) { h->sblk_base = vs.sblk; h->sblk_step = vs.fblk_bytes / sizeof(double); }
+      }
       fblk_off += vs.fblk_bytes;
       vs.fblk = base;
       vs.Usum = reinterpret_cast<float*>(base);
@@ -1006,7 +1029,7 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
       vs.Ma_G = reinterpret_cast<double*>(base + gblk_tsum_bytes(vs));
       vs.Md_G = vs.Ma_G + kk;
       vs.mu = vs.Md_G + kk;
-      vs.sblk = h->sblk_arena + (size_t)v * h->sblk_stride;
+      if (!h->sblk_embedded) vs.sblk = h->sblk_arena + (size_t)v * h->sblk_stride;
       if (!vs.owned) {                // (a G replica writes the same copies as the owner: nobody reads them here)
         vs.g_replica = true;
         if ((e = dev_alloc_zero(&vs.G32, (size_t)vs.m_pad * 64)) != hipSuccess) return bail(e, "hipMalloc G32");
@@ -2190,6 +2213,7 @@ int resnmtf_factor_device_ptr(resnmtf_handle* h, int v, int which, void** ptr, s
       if (!vs.sblk) return h->fail(RESNMTF_ERR_STATE, "no S exchange block: create the handle with replicate_gs = 1");
       *ptr = vs.sblk; *bytes = h->sblk_stride * sizeof(double); break;
     case RESNMTF_FACTOR_SBLOCK_ALL:
+      if (h->sblk_embedded) return h->fail(RESNMTF_ERR_STATE, "the S blocks of this handle sit inside the F blocks (RESNMTF_FACTOR_FBLOCK_ALL moves both)");
       if (!h->sblk_arena) return h->fail(RESNMTF_ERR_STATE, "no S exchange blocks: create the handle with replicate_gs = 1");
       *ptr = h->sblk_arena; *bytes = h->sblk_stride * sizeof(double) * h->V; break;
     default: return h->fail(RESNMTF_ERR_INVALID, "unknown factor selector");

@@ -140,6 +140,17 @@ class HipEngineAdapter:
             self._views[key] = torch.as_tensor(_CudaBlob(ptr, nbytes // 8), device="cuda")
         return self._views[key]
 
+    @property
+    def sblock_in_fblock(self) -> bool:
+        """True when the library keeps the S exchange block of a view at the end of its F exchange block (replicated
+        G / S chains, equal-shaped views): the all-gather of the F blocks then moves the S blocks too."""
+        try:
+            fptr, fbytes = self.e.factor_device_ptr(0, _WHICH["FBLOCK"])
+            sptr, sbytes = self.e.factor_device_ptr(0, _WHICH["SBLOCK"])
+        except Exception:
+            return False
+        return fptr <= sptr and sptr + sbytes <= fptr + fbytes
+
     def synchronize(self):
         self.e.synchronize()
 
@@ -283,9 +294,11 @@ class ShardedSweep:
         if self.replicate_gs and not getattr(self.engine, "supports_replicated_gs", engine is None and engine_factory is None):
             raise ValueError("replicate_gs needs an engine with the block phases (PHASE_XTF / G_ALL / XG / S_ALL)")
         self._allgather_blocks = self._can_allgather(engine_opts_allgather)
-        if self.replicate_gs and self._tstream is not None:       # three collectives between dependent steps: one stream
+        if self.replicate_gs and self._tstream is not None:       # collectives between dependent steps: one stream
             self._serial = True
             self._xstream = self._tstream
+        # S blocks inside the F blocks (the HIP library with equal-shaped views): two collectives per sweep instead of three
+        self._s_in_f = bool(self.replicate_gs and getattr(self.engine, "sblock_in_fblock", False))
         # all-gather layout: the exchange sits between two dependent steps of the sweep (nothing to overlap it
         # with), so it is issued on the compute stream itself -- measured with one rank on RCCL: 54.6 us per
         # sweep against 90.0 us through a second stream and its event edges
@@ -364,9 +377,15 @@ class ShardedSweep:
         self._gather_blocks("GBLOCK")
         self.engine.phase(r, PHASE_G_ALL, t)
         self.engine.phase(r, PHASE_XG, t)
-        self._gather_blocks("SBLOCK")
-        self.engine.phase(r, PHASE_S_ALL, t)
-        self._gather_blocks("FBLOCK")
+        if self._s_in_f:
+            # the F blocks carry the S blocks: one gather; S_ALL then writes the F coefficients of every view into the local
+            # copies of the blocks (every rank computes them for every view, what arrived in those slots is overwritten)
+            self._gather_blocks("FBLOCK")
+            self.engine.phase(r, PHASE_S_ALL, t)
+        else:
+            self._gather_blocks("SBLOCK")
+            self.engine.phase(r, PHASE_S_ALL, t)
+            self._gather_blocks("FBLOCK")
 
     def _bcast(self, v: int, which: str):
         t = self.engine.factor_tensor(v, which)
