@@ -708,7 +708,11 @@ double wide_makespan(int ntg, int nsplit, double d_long, double d_last, int n_cu
 }
 WidePlan plan_wide(int ntiles, int rows_pad, int KP, int kinds /* aux products, 0 = hand-off mode A */, int n_cu, int force_ns, int nw) {
   const double t_pass = 4.0 * ntiles * 64.0 * rows_pad / 5.0e6;          // us for the X bytes at 5 TB/s
-  const double t_kk = 12.0 + 50.0 * (KP / 64.0) * (KP / 64.0) * (KP / 64.0);      // tools/stamps.py: 53-63 us at k = 64, 17-18 at k = 32
+  // the k x k job of the last-arriving aux workgroup (tools/stamps.py, after its slab loads were batched): Xt.F launch (two aux
+  // kinds) 6 us at k = 32, 18 at k = 64; X.G launch (three kinds, the S rule and the error inside) 14 / 49 us; hand-off mode A
+  // (job in workgroup 0 for the whole launch): the earlier, slower figure
+  const double r3 = (KP / 64.0) * (KP / 64.0) * (KP / 64.0);
+  const double t_kk = kinds == 3 ? 9.0 + 40.0 * r3 : kinds == 2 ? 4.5 + 13.5 * r3 : 12.0 + 50.0 * r3;
   WidePlan best;
   double best_aux_time = 1e300;
   int last_na = -1;
