@@ -273,7 +273,7 @@ def run_sharded(args) -> dict:
         "config": {"workload": f"{cfg_name}: {n_views} views " + ",".join(f"{a}x{b}" for a, b in sorted(set(shapes), reverse=True))
                                + f", k={k}, " + "+".join(f"{key}={val:g}" for key, val in coupling.items())
                                + " (all rows / columns of coupled views shared), one view per GPU, Gauss-Seidel order kept exactly; "
-                               + (("F, G and S chains replicated on every rank, " + ("two" if getattr(drv, "_s_in_f", False) else "three") + " block all-gathers per sweep") if replicated_gs else
+                               + (("F, G and S chains replicated on every rank, " + ("two" if drv.collectives_per_sweep == 2 else "three") + " block all-gathers per sweep") if replicated_gs else
                                   ("F chain replicated on every rank (its inputs: one all-gather per sweep)" if allgather else
                                    "F chain replicated on every rank (its inputs broadcast once per sweep)") if replicated else
                                   "F exchanged by ordered broadcasts"),

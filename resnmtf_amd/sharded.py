@@ -324,6 +324,13 @@ class ShardedSweep:
                 all(b.numel() == size and b.data_ptr() == arena.data_ptr() + v * size * esz for v, b in enumerate(blocks)))
 
     @property
+    def collectives_per_sweep(self) -> int:
+        """Collectives between dependent steps of one sweep in the replicated-chains layouts (0: ordered broadcasts)."""
+        if self.replicate_gs:
+            return 2 if self._s_in_f else 3
+        return 1 if self._allgather_blocks else 0
+
+    @property
     def allgather_layout(self) -> bool:
         """True when the F exchange blocks travel by one all-gather per sweep (one view per rank, equal blocks)."""
         return self._allgather_blocks
