@@ -376,8 +376,9 @@ class ShardedSweep:
     def _sweep_replicated_gs(self, t: int):
         """One sweep with all three chains replicated (R/update_steps.r:282-314 in the reference's order):
             F chain (every view, every rank)  ->  Xt.F pass of the own view  ->  [T blocks]  ->  G chain (every view)
-            ->  X.G' pass of the own view + first half of its k x k job  ->  [S blocks]  ->  S chain, lambda, mu, error,
-            F coefficients (every view)  ->  [U blocks]"""
+            ->  X.G' pass of the own view + first half of its k x k job  ->  [U blocks with the S blocks inside]  ->  S chain,
+            lambda, mu, error, F coefficients (every view); engines that keep the S blocks apart: [S blocks] before the
+            S chain, [U blocks] after it"""
         r = self.rank
         self.engine.phase(r, PHASE_F_ALL, t)
         self.engine.phase(r, PHASE_XTF, t)
