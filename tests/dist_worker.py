@@ -269,6 +269,8 @@ def build_problem_gs(world, k=5):
     positions, a different weight per pair (tests/helpers.py coupled_problem): the replicated-chains layout."""
     from helpers import coupled_problem
     shapes = [(96 + 8 * v, 72 - 8 * (v % 2)) for v in range(world)]
+    if os.environ.get("RESNMTF_TEST_UNEVEN") == "1":      # row counts in different 64-row paddings: F blocks of different sizes
+        shapes = [(96 + 90 * v, 72 - 8 * (v % 2)) for v in range(world)]
     prob = coupled_problem(shapes, k, seed=31 + world, phi_w=1.5, psi_w=1.0, xi_w=0.4)
     prob.extras["shapes"] = shapes
     return prob

@@ -326,6 +326,21 @@ def test_wide_chain_one_process_bitwise(views, k, n, m):
             assert np.array_equal(x, y)
 
 
+@pytest.mark.gpu
+def test_sharded_hip_replicated_chains_unequal_blocks(tmp_path, monkeypatch):
+    """Views whose F exchange blocks differ in size (row counts in different paddings): the S blocks keep their own
+    arena and travel on their own (three exchanges per sweep, by broadcasts) -- same results against the oracle."""
+    monkeypatch.setenv("RESNMTF_TEST_UNEVEN", "1")
+    got = launch("gpu_gs", tmp_path, world=3, k=24)
+    assert bool(got["mirrors_ok"])
+    ref = oracle_reference_gs(3, k=24)
+    np.testing.assert_allclose(got["all_error"], ref["All_Error"], atol=2e-5, rtol=1e-4)
+    for v in range(3):
+        assert rel_fro(got[f"output_f{v}"], ref["output_f"][v]) < 2e-5
+        assert rel_fro(got[f"output_g{v}"], ref["output_g"][v]) < 2e-5
+        assert rel_fro(got[f"output_s{v}"], ref["output_s"][v]) < 1e-4
+
+
 def oracle_reference_gs(world, sweeps=12, k=5):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dist_worker
