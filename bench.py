@@ -5,9 +5,11 @@
 
 A "step" is one full sweep of update_matrices + calculate_error (R/main.r:84-108) over all
 views.  N = 1: BASELINE.json configs[1] (c2: one view 10000 x 2000, k = 16, synthetic planted
-blocks).  N > 1 (launched by torch.distributed.run, one rank per GPU): N
-phi-coupled c2-shaped views, one per GPU, F blocks exchanged through torch.distributed (RCCL)
-in the reference's Gauss-Seidel order -- weak scaling, per-GPU work fixed.
+blocks).  N = 2 / 4 / 8: BASELINE's c3 / c4 / c5, one view per GPU, one process per
+GPU over torch.distributed (RCCL), the reference's Gauss-Seidel order kept exactly.  Started either
+by ``python -m torch.distributed.run`` (RANK / WORLD_SIZE in the environment) or plainly as
+``python bench.py --gpus N``: the ranks are then started here as CHILD processes, before anything in
+this process touches the GPU, and rank 0's JSON line is relayed.
 
 ``value`` = view-updates per second = steps x n_views / wall (inputs resident in HBM before the
 timed region).  Rank 0 prints ONE JSON line.
@@ -30,9 +32,10 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 METRIC = "multiplicative-update iters/sec (all views)"
 
 
-def cpu_baseline(prob, warm: int = 3, timed: int = 20) -> dict:
+def cpu_baseline(prob, warm: int = 3, timed: int = 20, budget_s: float = 0.0, note: str = "the same workload") -> dict:
     """The oracle (literal fp64 restatement: four passes over X per sweep, materialised
-    residual -- the BLAS call sequence R would issue) on the host cores; NumPy/OpenBLAS."""
+    residual -- the BLAS call sequence R would issue) on the host cores; NumPy/OpenBLAS.
+    ``budget_s`` > 0: the number of timed sweeps is cut so that the sample takes about that long (large views)."""
     from oracle import resnmtf_oracle as O
     try:
         from threadpoolctl import threadpool_info
@@ -51,14 +54,18 @@ def cpu_baseline(prob, warm: int = 3, timed: int = 20) -> dict:
         cur_f, cur_s, cur_g, lam, mu = O.update_matrices(data, cur_f, cur_s, cur_g, lam, mu, prob.phi, prob.xi,
                                                          prob.psi, ri, ci, rn, cn)
         return O.calculate_error(data, cur_f, cur_s, cur_g, norms)
+    t_w = time.perf_counter()
     for _ in range(warm):
         sweep()
+    per = (time.perf_counter() - t_w) / max(warm, 1)
+    if budget_s > 0.0:
+        timed = int(max(2, min(timed, budget_s / max(per, 1e-9))))
     t0 = time.perf_counter()
     for _ in range(timed):
         sweep()
     dt = time.perf_counter() - t0
     return {"value": timed * len(data) / dt, "unit": "view-updates/s", "cores": int(threads), "kind": "port",
-            "sample": f"{timed} sweeps (after {warm} warm-up) of the same workload, NumPy+OpenBLAS fp64, "
+            "sample": f"{timed} sweeps (after {warm} warm-up) of {note}, NumPy+OpenBLAS fp64, "
                       f"{threads} threads; R unavailable on the box"}
 
 
@@ -119,10 +126,13 @@ def run_single(args) -> dict:
         return e, up
 
     eng, upload_s = make_engine()
+    t_cold = time.perf_counter()
     # one-off costs of a new handle stay outside the timed region, as a compile cache would: the library captures a
     # hipGraph per run length at the first run of that length (resnmtf_run) -- run the timed length once, put the
     # initial factors back, then the W warm-up sweeps and the K timed ones start from the initial state as always
     eng.run(args.steps)
+    torch.cuda.synchronize()
+    cold_s = time.perf_counter() - t_cold
     eng.set_factors(0, prob.init_f[0], prob.init_s[0], prob.init_g[0])
     if args.warmup > 0:
         eng.run(args.warmup)
@@ -165,7 +175,10 @@ def run_single(args) -> dict:
         "config": {"workload": "c2: 1 view 10000x2000, k=16, fixed sweeps (BASELINE.json configs[1])",
                    "n_views": 1, "rows": n, "cols": m, "k": k, "final_error": float(errs[-1]),
                    "arithmetic": "fp32 X + f32 MFMA accumulate for X.G / Xt.F; fp64 factors and epilogues",
-                   "upload_s_pcie_inclusive": round(upload_s, 4), "opt_in_x_u16": alt},
+                   "upload_s_pcie_inclusive": round(upload_s, 4), "opt_in_x_u16": alt,
+                   # the timed call replays a hipGraph of exactly `steps` sweeps that an untimed call of the same length
+                   # captured before the warm-up (as a compile cache would); a cold first call of that length took:
+                   "precaptured_graph": True, "first_run_incl_capture_s": round(cold_s, 5)},
         "roofline": roofline, "cpu_baseline": cpu,
     }
 
@@ -174,6 +187,18 @@ def _all_gather_ints(dist, value: int, world: int):
     out = [None] * world
     dist.all_gather_object(out, int(value))
     return out
+
+
+def _make_driver(sharded, prob, n_views, rank, world, local_rank, **extra):
+    return sharded.ShardedSweep(prob, owner_of=list(range(n_views)), rank=rank, world=world, device_index=local_rank,
+                                replicate_f=("force" if os.environ.get("RESNMTF_FORCE_REPLICATE") == "1" else
+                                             os.environ.get("RESNMTF_NO_REPLICATE") != "1"),
+                                allgather_blocks=(os.environ.get("RESNMTF_NO_ALLGATHER") != "1"),
+                                **({"replicate_gs": False} if os.environ.get("RESNMTF_NO_REPLICATE_GS") == "1" else {}),
+                                **({"slice_chains": os.environ["RESNMTF_SLICE_CHAINS"] == "1"} if "RESNMTF_SLICE_CHAINS" in os.environ else {}),
+                                **({"overlap_u": False} if os.environ.get("RESNMTF_NO_OVERLAP") == "1" else {}),
+                                **({"serial_exchange": os.environ["RESNMTF_SERIAL_EXCHANGE"] == "1"}
+                                   if "RESNMTF_SERIAL_EXCHANGE" in os.environ else {}), **extra)
 
 
 def run_sharded(args) -> dict:
@@ -185,7 +210,7 @@ def run_sharded(args) -> dict:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # rehearsal on a one-GPU box: RESNMTF_BENCH_DEVICE pins every rank to one device and
     # RESNMTF_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU); never set by the driver
@@ -201,33 +226,33 @@ def run_sharded(args) -> dict:
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     n_views = world
     # BASELINE.json configs[2..4]: c3 on 2 GPUs, c4 on 4, c5 on 8 (one view per GPU); any other N -- or
-    # RESNMTF_BENCH_SAME_SHAPE=1 -- N phi-coupled c2-shaped views (per-GPU work as at N = 1)
+    # RESNMTF_BENCH_SAME_SHAPE=1 -- N phi-coupled c2-shaped views (per-GPU work as at N = 1).  RESNMTF_BENCH_SHAPE=n,m,k:
+    # N fully coupled views of that shape (rehearsals at small sizes)
     table = {2: ("c3", [(10000, 2000), (10000, 1500)], 16, dict(phi=200.0)),
              4: ("c4", [(20000, 4000)] * 4, 32, dict(phi=200.0, psi=200.0)),
              8: ("c5", [(50000, 8000)] * 8, 64, dict(phi=200.0, xi=200.0, psi=200.0))}
-    if world in table and os.environ.get("RESNMTF_BENCH_SAME_SHAPE") != "1":
+    if os.environ.get("RESNMTF_BENCH_SHAPE"):
+        sn, sm, sk = (int(x) for x in os.environ["RESNMTF_BENCH_SHAPE"].split(","))
+        cfg_name, shapes, k, coupling = f"{world} x {sn}x{sm}", [(sn, sm)] * world, sk, dict(phi=200.0, xi=200.0, psi=200.0)
+    elif world in table and os.environ.get("RESNMTF_BENCH_SAME_SHAPE") != "1":
         cfg_name, shapes, k, coupling = table[world]
     else:
         cfg_name, shapes, k, coupling = f"{world} x c2", [(10000, 2000)] * world, 16, dict(phi=200.0)
     n, m = shapes[rank]
     # every rank builds only the view it owns (same seeds as synth.make_problem) + all initial factors
     prob = sharded.local_problem(n_views, shapes, k, owned=[rank], **coupling)
-    drv = sharded.ShardedSweep(prob, owner_of=list(range(n_views)), rank=rank, world=world, device_index=local_rank,
-                               replicate_f=("force" if os.environ.get("RESNMTF_FORCE_REPLICATE") == "1" else
-                                            os.environ.get("RESNMTF_NO_REPLICATE") != "1"),
-                               allgather_blocks=(os.environ.get("RESNMTF_NO_ALLGATHER") != "1"),
-                               **({"replicate_gs": False} if os.environ.get("RESNMTF_NO_REPLICATE_GS") == "1" else {}),
-                               **({"serial_exchange": os.environ["RESNMTF_SERIAL_EXCHANGE"] == "1"}
-                                  if "RESNMTF_SERIAL_EXCHANGE" in os.environ else {}))
+    drv = _make_driver(sharded, prob, n_views, rank, world, local_rank)
     if os.environ.get("RESNMTF_FORCE_BCAST") == "1":      # rehearsal: issue the F broadcast even with one rank
         drv.plan[0]["F"] = True
     drv.reserve(args.warmup + args.steps + 8)      # per-sweep error slots for both run() calls
     # RESNMTF_SHARDED_GRAPH=K (opt-in, RCCL only): K sweeps incl. their collectives replayed from one captured graph
     chunk = int(os.environ.get("RESNMTF_SHARDED_GRAPH", "0")) if backend == "nccl" else 0
     drv.run(args.warmup, graph_chunk=chunk)
+    drv.collect()
     dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     drv.run(args.steps, graph_chunk=chunk)
+    drv.collect()                                  # (sliced chains: the owners' fp64 F / G whole again -- part of the job)
     dist.barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -237,53 +262,133 @@ def run_sharded(args) -> dict:
     replicated = any(drv.replicated)
     allgather = drv.allgather_layout
     replicated_gs = drv.replicate_gs
+    sliced = drv.sliced
+    per_sweep = drv.collectives_per_sweep
+    overlapped = getattr(drv, "_group_u", None) is not None
     n_devices = len({int(d) for d in _all_gather_ints(dist, local_rank, world)})
     drv.close()
+    # ---- roofline leg: the same sharded sweep, every rank, eager, every kernel of the library timed by HIP events attached
+    # to its dispatch (resnmtf_kernel_timings): the streaming passes (dominant) AND the chain / pack kernels of the layout
     roofline = None
-    if rank == 0:      # the same streaming passes (rank 0's own view, same shape) timed per launch while the others wait
-        from resnmtf_amd.engine import Engine
-
-        def make_engine(**kw):
-            e = Engine([n], [m], [k], device_id=local_rank, **kw)
-            e.set_view(0, prob.data[0])
-            e.set_restrictions(None, None, None)
-            e.set_factors(0, prob.init_f[0], prob.init_s[0], prob.init_g[0])
-            return e, 0.0
+    kt = None
+    t_steps = max(2, min(args.steps, 30))
+    try:
+        drv_t = _make_driver(sharded, prob, n_views, rank, world, local_rank, time_kernels=True)
+        drv_t.reserve(t_steps + 8)
+        drv_t.run(2)
+        torch.cuda.synchronize()
+        drv_t.engine.kernel_timings(reset=True); drv_t.engine.e.pass_timings(reset=True)
+        drv_t.run(t_steps)
+        torch.cuda.synchronize()
+        kt = drv_t.engine.kernel_timings()
+        pt = drv_t.engine.e.pass_timings()
+        drv_t.close()
+    except Exception as exc:          # never lose the bench line to the extra leg
+        print(f"[bench] rank {rank}: timed leg failed: {exc}", file=sys.stderr)
+    single = None
+    if rank == 0 and kt is not None:
+        launches = pt["xg_launches"] + pt["xtf_launches"]
+        pass_ms = (pt["xg_ms_total"] + pt["xtf_ms_total"]) / max(launches, 1)
+        bytes_per_launch = (pt["xg_bytes"] * pt["xg_launches"] + pt["xtf_bytes"] * pt["xtf_launches"]) / max(launches, 1)
+        achieved = bytes_per_launch / (pass_ms * 1e-3) / 1e9
+        per_kind = {name: round(ms / t_steps * 1e3, 2) for name, (ms, cnt) in kt.items() if cnt}
+        roofline = {"bound": "hbm", "kernel": "pass_kernel (X.G and Xt.F streaming passes of rank 0's view inside the SHARDED sweep)",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": None, "avg_launch_us": round(pass_ms * 1e3, 3), "launches": int(launches),
+                    "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "rank0_kernel_us_per_sweep": per_kind, "rank0_kernel_us_per_sweep_total": round(sum(per_kind.values()), 2),
+                    "note": "HIP events on every library launch of rank 0 during a separate eager leg of the same sharded sweep "
+                            f"({t_steps} sweeps); f_chain / g_chain / s_chain / pack = the layout's chain, fold / slice kernels"}
+    dist.barrier()
+    if rank == 0:      # the one-view rate of rank 0's shape (the denominator of a retention figure), others wait
         try:
-            roofline = pass_roofline(make_engine, min(args.steps, 200), args.warmup)
-            roofline["note"] = "rank 0's view alone (uncoupled), after the timed region"
-            e1, _ = make_engine()
+            from resnmtf_amd.engine import Engine
+            e1 = Engine([n], [m], [k], device_id=local_rank)
+            e1.set_view(0, prob.data[0]); e1.set_restrictions(None, None, None)
+            e1.set_factors(0, prob.init_f[0], prob.init_s[0], prob.init_g[0])
             e1.run(min(args.steps, 50)); e1.run(3)
             torch.cuda.synchronize(); t1 = time.perf_counter()
             e1.run(min(args.steps, 50))
             torch.cuda.synchronize()
-            roofline["single_view_updates_per_s"] = round(min(args.steps, 50) / (time.perf_counter() - t1), 2)
+            single = round(min(args.steps, 50) / (time.perf_counter() - t1), 2)
             e1.close()
-        except Exception as exc:      # never lose the bench line to the extra leg
-            roofline = None
-            print(f"[bench] roofline leg failed: {exc}", file=sys.stderr)
+            if roofline is not None:
+                roofline["single_view_updates_per_s"] = single
+        except Exception as exc:
+            print(f"[bench] single-view leg failed: {exc}", file=sys.stderr)
     dist.barrier()
     dist.destroy_process_group()
     if rank != 0:
         return {}
+    # CPU baseline at N > 1: ONE view of the workload (rank 0's, uncoupled) on the host cores, a bounded sample;
+    # the other ranks have left, every core is free
+    cpu = None
+    if not args.no_cpu_baseline:
+        try:
+            one = synth.Problem([prob.data[0]], [prob.init_f[0]], [prob.init_s[0]], [prob.init_g[0]], np.zeros((1, 1)), np.zeros((1, 1)),
+                                np.zeros((1, 1)), k, "one view")
+            one.row_names = [prob.row_names[0]]; one.col_names = [prob.col_names[0]]
+            cpu = cpu_baseline(one, warm=1, timed=20, budget_s=15.0,
+                               note=f"ONE of the {n_views} views ({n}x{m}, k={k}; coupling terms left out: O(n k) beside the four X passes)")
+        except Exception as exc:
+            print(f"[bench] cpu baseline failed: {exc}", file=sys.stderr)
+    layout = (("F and G chains ROW-SLICED over the ranks (all-to-all of row slices), S chain replicated; "
+               f"{per_sweep} collectives per sweep between dependent steps" + (", U slices on a second communicator beside the S chain" if overlapped else ""))
+              if sliced else
+              ("F, G and S chains replicated on every rank, " + ("two" if per_sweep == 2 else "three") + " block all-gathers per sweep") if replicated_gs else
+              ("F chain replicated on every rank (its inputs: one all-gather per sweep)" if allgather else
+               "F chain replicated on every rank (its inputs broadcast once per sweep)") if replicated else
+              "F exchanged by ordered broadcasts")
     return {
         "metric": METRIC, "value": round(args.steps * n_views / dt, 2), "unit": "view-updates/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{cfg_name}: {n_views} views " + ",".join(f"{a}x{b}" for a, b in sorted(set(shapes), reverse=True))
                                + f", k={k}, " + "+".join(f"{key}={val:g}" for key, val in coupling.items())
-                               + " (all rows / columns of coupled views shared), one view per GPU, Gauss-Seidel order kept exactly; "
-                               + (("F, G and S chains replicated on every rank, " + ("two" if drv.collectives_per_sweep == 2 else "three") + " block all-gathers per sweep") if replicated_gs else
-                                  ("F chain replicated on every rank (its inputs: one all-gather per sweep)" if allgather else
-                                   "F chain replicated on every rank (its inputs broadcast once per sweep)") if replicated else
-                                  "F exchanged by ordered broadcasts"),
+                               + " (all rows / columns of coupled views shared), one view per GPU, Gauss-Seidel order kept exactly; " + layout,
                    "n_views": n_views, "shapes": [list(sh) for sh in shapes], "k": k,
                    "backend": ("rccl" if backend == "nccl" else backend), "world_size": world, "distinct_devices": n_devices,
                    "final_error": float(errs[-1]) if len(errs) else None,
                    "scaling_note": "BASELINE.json prescribes a different workload per GPU count (c3 / c4 / c5): compare value / n_gpus "
                                    "with the one-view rate of the same shape (roofline.single_view_updates_per_s), not across N"},
-        "roofline": roofline, "cpu_baseline": None,
+        "roofline": roofline, "cpu_baseline": cpu,
     }
+
+
+def spawn_ranks(args) -> int:
+    """``python bench.py --gpus N`` without a launcher: start the N ranks as child processes (one per GPU, rendezvous on
+    127.0.0.1) BEFORE this process has touched the GPU -- it never does -- and relay rank 0's JSON line.  No exec."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()                     # (the exact child this process started)
+            p.wait()
+        rc = rc or p.returncode
+    line = None
+    for ln in (out or b"").decode(errors="replace").splitlines():
+        if ln.startswith("{"):
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if line:
+        print(line, flush=True)
+    return rc if rc else (0 if line else 1)
 
 
 def main():
@@ -296,6 +401,8 @@ def main():
     # RESNMTF_FORCE_SHARDED=1 exercises the multi-rank code path (nccl init, ordered exchange driver,
     # barrier/max timing) with a single rank -- a rehearsal on the one-GPU box
     sharded_path = args.gpus > 1 or os.environ.get("RESNMTF_FORCE_SHARDED") == "1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # plain `python bench.py --gpus N`: this process only starts the ranks
+        raise SystemExit(spawn_ranks(args))
     out = run_sharded(args) if sharded_path else run_single(args)
     if out:
         print(json.dumps(out), flush=True)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RESNMTF_ABI_VERSION 1
+#define RESNMTF_ABI_VERSION 2   /* 2: options gained wait_mode and the sliced-chain fields, bf16_split = 1 is refused, new phases / selectors / entry points */
 #define RESNMTF_MAX_K 64
 
 enum {
@@ -54,7 +54,21 @@ enum { RESNMTF_FACTOR_F = 0, RESNMTF_FACTOR_G = 1, RESNMTF_FACTOR_S = 2,
        RESNMTF_FACTOR_SBLOCK_ALL = 8 /* ... of all views, contiguous in view order (equal k: equal blocks).  With equal-shaped
                                         views the S block of a view sits at the end of its F block instead (the address
                                         RESNMTF_FACTOR_SBLOCK returns lies inside RESNMTF_FACTOR_FBLOCK's range): gathering
-                                        the F blocks after RESNMTF_PHASE_XG moves both, and this selector is refused */ };
+                                        the F blocks after RESNMTF_PHASE_XG moves both, and this selector is refused */,
+       /* slice_chains: the buffers of the four all-to-all exchanges of a sweep (fp32; V equal chunks each, chunk c = what
+        * rank c receives / what came from rank c; `v` is ignored beyond its range check) */
+       RESNMTF_FACTOR_U_SEND = 9,    /* own view's U = X.G' folded, cut into V row slices          [V][rows_per_slice][KP] */
+       RESNMTF_FACTOR_U_RECV = 10,   /* rows of MY slice of every view's U                          (same shape) */
+       RESNMTF_FACTOR_FNEW_SEND = 11,/* new F rows of my slice of every view (compact f32)         [V][rows_per_slice][KP] */
+       RESNMTF_FACTOR_FNEW_RECV = 12,/* the own view's new F, all rows, as the V slice holders sent them */
+       RESNMTF_FACTOR_T_SEND = 13,   /* own view's T = Xt.F' in V column slices, each followed by Ma_G | Md_G (fp64) */
+       RESNMTF_FACTOR_T_RECV = 14,
+       RESNMTF_FACTOR_GNEW_SEND = 15,
+       RESNMTF_FACTOR_GNEW_RECV = 16,
+       RESNMTF_FACTOR_F_SLICE = 17,  /* the rows of MY slice of view v's fp64 F (a range inside RESNMTF_FACTOR_F): during a sliced
+                                        run these are the only rows of any view's F this rank keeps current -- collect the
+                                        slices (all-gather) before reading a whole factor */
+       RESNMTF_FACTOR_G_SLICE = 18 };
 
 /* phases of one view's update inside a sweep (R/update_steps.r:282-314) */
 enum {
@@ -77,7 +91,14 @@ enum {
   RESNMTF_PHASE_G_ALL = 6 /* update_g of EVERY view, in view order (R/update_steps.r:180-207, :295-303) from the G blocks */,
   RESNMTF_PHASE_XG = 7    /* X.G' pass of owned view v + first half of its k x k job (inputs of the S rule -> S block) +
                              fold of U into the F block */,
-  RESNMTF_PHASE_S_ALL = 8 /* update_s, update_lm, error and the F coefficients of EVERY view (s_chain_kernel) */
+  RESNMTF_PHASE_S_ALL = 8 /* update_s, update_lm, error and the F coefficients of EVERY view (s_chain_kernel) */,
+  /* slice_chains (view argument = the owned view):
+   *   sweep = SLICE_F, [all-to-all: new F rows -> owners], SLICE_XTF, [all-to-all: T slices + G coefficients],
+   *           SLICE_G, [all-to-all: new G rows -> owners], SLICE_XG, [all-gather S blocks] S_ALL  ||  [all-to-all: U slices] */
+  RESNMTF_PHASE_SLICE_F = 9   /* update_f of EVERY view on MY row slice, in view order (R/update_steps.r:141-165, :282-287) */,
+  RESNMTF_PHASE_SLICE_XTF = 10 /* received F rows -> operand copies; Xt.F pass + k x k job of the owned view; T cut into slices */,
+  RESNMTF_PHASE_SLICE_G = 11  /* update_g of EVERY view on MY column slice (R/update_steps.r:180-207, :295-303) */,
+  RESNMTF_PHASE_SLICE_XG = 12 /* received G rows -> operand copies; X.G' pass + first half of the k x k job (S block); U cut into slices */
 };
 
 typedef struct resnmtf_handle resnmtf_handle;
@@ -110,8 +131,8 @@ typedef struct resnmtf_options {
                                v_mfma_f32_16x16x32_bf16 per product group in WIDE workgroups (8 or 4 tiles share one
                                LDS copy of the factor block) -- dropped terms <= 2^-26: f32-grade (F / G 2e-7 ... 7e-6
                                from the fp64 reference, the f32 MFMA 1e-7 ... 6e-6);
-                             1 accepted as an alias of 0 (the former two-piece form is retired: the K = 32 three-piece
-                               form is faster than it was);
+                             1 refused (RESNMTF_ERR_INVALID): the former two-piece form is retired -- callers that asked
+                               for its speed / precision trade must choose 0 or 2 knowingly;
                              2 plain v_mfma_f32_16x16x4_f32, one tile per workgroup */
   int replicate_f;        /* view-sharded use (phase API): 1 = every rank keeps, for EVERY view, the inputs of its F
                              update (X.G folded into one f32 slab, the two k x k coefficient matrices, lambda) in one
@@ -139,6 +160,21 @@ typedef struct resnmtf_options {
                              three, S blocks on their own, when the views' F blocks differ in size) instead of
                              2 V ordered broadcasts, and the two streaming passes of all ranks run at the same time
                              (psi / xi coupling; R/update_steps.r:195-204, :231-237).  Needs equal k in all views. */
+  int wait_mode;          /* how a fixed-iteration resnmtf_run waits for the device: 0 (default) polls the sweep counter the last
+                             k x k job mirrors into pinned host memory -- the call returns when the counter arrives, which can be
+                             up to ~100 us BEFORE the stream has drained (every other entry point synchronises first), and the
+                             calling thread spins (with pauses) meanwhile, at most 20 ms without progress before it falls back to
+                             a stream synchronisation; 1 = hipStreamSynchronize (blocks, ~10-15 us later per call) */
+  int slice_chains;       /* view-sharded use, with replicate_f and replicate_gs: 1 = ROW-SLICED chains.  star_prod_relevant is
+                             row-local by name (R/utils.r:67-73), so instead of every rank walking the whole F (G) chain of all
+                             V views, rank r walks it for the 1 / V of the shared rows (columns) it is assigned
+                             (RESNMTF_PHASE_SLICE_F / _G): one view's worth of element-wise work per rank.  The rows travel by
+                             all-to-all (the RESNMTF_FACTOR_*_SEND / _RECV buffers), the S chain stays replicated (k x k).  Needs
+                             one owned view per handle (view index = slice_index), slice_count = number of views <= 8, equal
+                             shapes and k, every coupled pair sharing ALL rows / columns in the same order (identity maps);
+                             hand-off mode B is used at every k.  Otherwise fall back to replicate_gs. */
+  int slice_index;        /* which slice this handle walks (= the rank) */
+  int slice_count;        /* number of slices (= ranks = views) */
 } resnmtf_options;
 
 typedef struct resnmtf_pass_timing {
@@ -273,6 +309,9 @@ int resnmtf_set_shared_cols(resnmtf_handle* h, int v, int w, int count, const in
  * all_err[t] receives mean over views of ||X - F S G^T||_F^2 / ||X||_F^2 after sweep t
  * (All_Error, R/main.r:78,104); err_capacity is the length of all_err.  iters_done receives
  * the number of sweeps executed.  May be called repeatedly; state carries over.
+ * Fixed-iteration runs wait on a host-mapped sweep counter (options.wait_mode = 0): the call may return while the stream is
+ * still draining the last launch's workgroups, and the calling thread polls meanwhile -- see resnmtf_options.wait_mode;
+ * every other entry point, resnmtf_synchronize included, waits for the stream.
  */
 int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, double* all_err,
                 int err_capacity, int* iters_done);
@@ -317,6 +356,22 @@ int resnmtf_view_errors(resnmtf_handle* h, int v, int first, int count, double* 
 int resnmtf_synchronize(resnmtf_handle* h);
 /* Accumulated streaming-pass timings (options.time_kernels = 1); reset when reset != 0. */
 int resnmtf_pass_timings(resnmtf_handle* h, resnmtf_pass_timing* out, int reset);
+/* The same for the other kernels of a view-sharded sweep (options.time_kernels = 1, phase API): summed duration (ms) and
+ * launch count per kind -- RESNMTF_TIMED_* below; both arrays have RESNMTF_TIMED_KINDS entries. */
+enum { RESNMTF_TIMED_XG = 0, RESNMTF_TIMED_XTF = 1, RESNMTF_TIMED_F_CHAIN = 2, RESNMTF_TIMED_G_CHAIN = 3, RESNMTF_TIMED_S_CHAIN = 4,
+       RESNMTF_TIMED_PACK = 5 /* folds, slice pack / unpack */, RESNMTF_TIMED_KINDS = 6 };
+int resnmtf_kernel_timings(resnmtf_handle* h, double* ms_total, long long* launches, int reset);
+
+/* Phase API, convergence mode (R/main.r:50-81): tol >= 0 makes every phase enqueued from now on a checked one -- the S chain
+ * of a sweep (RESNMTF_PHASE_S_ALL; every rank holds the full per-view error table) evaluates
+ * |mean_t - mean_{t-1}| <= tol on the device and sets the stop flag, after which every kernel of the phases returns at
+ * once; tol < 0 (default) = fixed sweeps.  Identical bytes on every rank: all ranks stop on the same sweep.
+ * resnmtf_loop_state synchronises and reports the sweeps closed since resnmtf_prepare, the flag and the sweep count at
+ * which it fired (any pointer may be NULL). */
+int resnmtf_set_stop_tolerance(resnmtf_handle* h, double tol);
+int resnmtf_loop_state(resnmtf_handle* h, int* sweeps_done, int* done, int* stop_sweep);
+/* slice_chains: rows / columns per slice (multiples of 32; slice r covers [r * per_slice, min((r + 1) * per_slice, n))). */
+int resnmtf_slice_info(resnmtf_handle* h, int* rows_per_slice, int* cols_per_slice);
 
 #ifdef __cplusplus
 }

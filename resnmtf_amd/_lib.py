@@ -18,6 +18,11 @@ FACTOR_F, FACTOR_G, FACTOR_S, FACTOR_FBLOCK, FACTOR_FBLOCK_ALL = 0, 1, 2, 3, 4
 FACTOR_GBLOCK, FACTOR_GBLOCK_ALL, FACTOR_SBLOCK, FACTOR_SBLOCK_ALL = 5, 6, 7, 8
 PHASE_F, PHASE_G, PHASE_S, PHASE_F_ALL, PHASE_LOCAL_SWEEP = 0, 1, 2, 3, 4
 PHASE_XTF, PHASE_G_ALL, PHASE_XG, PHASE_S_ALL = 5, 6, 7, 8
+PHASE_SLICE_F, PHASE_SLICE_XTF, PHASE_SLICE_G, PHASE_SLICE_XG = 9, 10, 11, 12
+FACTOR_U_SEND, FACTOR_U_RECV, FACTOR_FNEW_SEND, FACTOR_FNEW_RECV = 9, 10, 11, 12
+FACTOR_T_SEND, FACTOR_T_RECV, FACTOR_GNEW_SEND, FACTOR_GNEW_RECV, FACTOR_F_SLICE, FACTOR_G_SLICE = 13, 14, 15, 16, 17, 18
+TIMED_KINDS = ("xg", "xtf", "f_chain", "g_chain", "s_chain", "pack")
+ABI_VERSION = 2
 MAX_K = 64
 
 
@@ -35,6 +40,7 @@ class Options(C.Structure):
         ("pass_splits_xtf", C.c_int), ("pass_lds_pad_kb", C.c_int), ("update_blocks", C.c_int),
         ("no_pitch_pad", C.c_int), ("kk_mode", C.c_int), ("bf16_split", C.c_int), ("replicate_f", C.c_int),
         ("no_f_chain", C.c_int), ("x_half", C.c_int), ("half_unroll", C.c_int), ("replicate_gs", C.c_int),
+        ("wait_mode", C.c_int), ("slice_chains", C.c_int), ("slice_index", C.c_int), ("slice_count", C.c_int),
     ]
 
 
@@ -82,6 +88,10 @@ SIGNATURES = {
     "resnmtf_synchronize": (C.c_int, [_h]),
     "resnmtf_pass_timings": (C.c_int, [_h, C.POINTER(PassTiming), C.c_int]),
     "resnmtf_view_image_info": (C.c_int, [_h, C.c_int, _ip, _dp]),
+    "resnmtf_kernel_timings": (C.c_int, [_h, _dp, C.POINTER(C.c_longlong), C.c_int]),
+    "resnmtf_set_stop_tolerance": (C.c_int, [_h, C.c_double]),
+    "resnmtf_loop_state": (C.c_int, [_h, _ip, _ip, _ip]),
+    "resnmtf_slice_info": (C.c_int, [_h, _ip, _ip]),
 }
 
 _lib = None
@@ -126,7 +136,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.resnmtf_abi_version() != 1:
+    if lib.resnmtf_abi_version() != ABI_VERSION:
         raise ImportError("libresnmtf_hip.so ABI version mismatch")
     _lib = lib
     return lib

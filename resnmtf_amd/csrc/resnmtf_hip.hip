@@ -131,6 +131,19 @@ struct resnmtf_handle {
   double* sblk_arena = nullptr; size_t sblk_stride = 0;        //   (S blocks: sblk_stride doubles each)
   bool sblk_embedded = false;         // the S block of a view sits at the end of its F block (equal-shaped views): they travel together
   double* sblk_base = nullptr; size_t sblk_step = 0;           // S block of view v = sblk_base + v * sblk_step (doubles)
+  int* view_sweep = nullptr;          // replicate_gs: [V] sweeps closed per view (s_chain_kernel) + [1] its arrival counter
+  double phase_tol = -1.0;            // phase API: >= 0 = convergence mode (resnmtf_set_stop_tolerance)
+  // slice_chains: rank r walks the F (G) chain of every view on the row (column) slice r; exchange buffers of the four
+  // all-to-alls of a sweep (V chunks each) and the two chain launches
+  bool sliced = false;
+  int sl_rows = 0, sl_cols = 0;       // rows / columns per slice (multiples of 32)
+  char *u_send = nullptr, *u_recv = nullptr, *t_send = nullptr, *t_recv = nullptr;
+  size_t u_chunk = 0, t_chunk = 0;    // bytes per chunk: [per_slice][KP] f32 (+ the fp64 tail Ma_G | Md_G for T)
+  float *f_send = nullptr, *f_recv = nullptr, *g_send = nullptr, *g_recv = nullptr;      // [V][per_slice][KP] f32 each
+  WideChainArgs<8> schain[2]{};       // SLICE_F ([0]) / SLICE_G ([1])
+  int schain_grid[2] = {0, 0};
+  double ktime_ms[RESNMTF_TIMED_KINDS] = {0, 0, 0, 0, 0, 0};     // time_kernels: per kind (resnmtf_kernel_timings)
+  long long klaunch[RESNMTF_TIMED_KINDS] = {0, 0, 0, 0, 0, 0};
   // pass timing (eager mode)
   std::vector<hipEvent_t> ev;         // pairs
   std::vector<int> ev_kind;           // 0 = xg, 1 = xtf per pair
@@ -162,6 +175,21 @@ hipError_t dev_alloc_zero(T** p, size_t count) {
   if (e != hipSuccess) return e;
   return hipMemset(*p, 0, std::max<size_t>(count, 1) * sizeof(T));
 }
+
+// time_kernels: a pair of events for one launch of the given kind (RESNMTF_TIMED_*), attached to the dispatch itself
+bool take_events(resnmtf_handle* h, int kind, hipEvent_t* e0, hipEvent_t* e1) {
+  if (!h->opt.time_kernels || h->ev_used + 2 > h->ev.size()) return false;
+  *e0 = h->ev[h->ev_used]; *e1 = h->ev[h->ev_used + 1];
+  h->ev_kind[h->ev_used / 2] = kind;
+  h->ev_used += 2;
+  return true;
+}
+#define LAUNCH_TIMED(h, kind, kern, grid, block, smem, ...)                                                        \
+  do {                                                                                                             \
+    hipEvent_t e0_ = nullptr, e1_ = nullptr;                                                                       \
+    if (take_events(h, kind, &e0_, &e1_)) hipExtLaunchKernelGGL(kern, grid, block, smem, (h)->stream, e0_, e1_, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern, grid, block, smem, (h)->stream, __VA_ARGS__);                                     \
+  } while (0)
 
 void free_view(ViewState& v) {
   if (v.fblk) { v.fblk = nullptr; v.Usum = nullptr; v.Ma_F = nullptr; v.Md_F = nullptr; v.lambda = nullptr; }   // arena slices
@@ -267,8 +295,16 @@ hipError_t set_all_attrs() {
 #define WCHAIN_ATTR(KPV, G, NVBV) TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_chain_kernel<KPV, G, NVBV>), \
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_chain_smem_bytes(KPV)))
   WCHAIN_ATTR(32, false, 4); WCHAIN_ATTR(32, true, 4); WCHAIN_ATTR(32, false, 8); WCHAIN_ATTR(32, true, 8);
+  WCHAIN_ATTR(48, false, 4); WCHAIN_ATTR(48, true, 4); WCHAIN_ATTR(48, false, 8); WCHAIN_ATTR(48, true, 8);
   WCHAIN_ATTR(64, false, 4); WCHAIN_ATTR(64, true, 4); WCHAIN_ATTR(64, false, 8); WCHAIN_ATTR(64, true, 8);
 #undef WCHAIN_ATTR
+#define SCHAIN_ATTR(KPV, G, NVBV) TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_chain_kernel<KPV, G, NVBV, true>), \
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_chain_smem_bytes(KPV)))
+  SCHAIN_ATTR(16, false, 4); SCHAIN_ATTR(16, true, 4); SCHAIN_ATTR(16, false, 8); SCHAIN_ATTR(16, true, 8);
+  SCHAIN_ATTR(32, false, 4); SCHAIN_ATTR(32, true, 4); SCHAIN_ATTR(32, false, 8); SCHAIN_ATTR(32, true, 8);
+  SCHAIN_ATTR(48, false, 4); SCHAIN_ATTR(48, true, 4); SCHAIN_ATTR(48, false, 8); SCHAIN_ATTR(48, true, 8);
+  SCHAIN_ATTR(64, false, 4); SCHAIN_ATTR(64, true, 4); SCHAIN_ATTR(64, false, 8); SCHAIN_ATTR(64, true, 8);
+#undef SCHAIN_ATTR
 #define CHAIN_ATTR(NVB, PFV) TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&f_chain_kernel<NVB, PFV>), \
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)f_chain_smem_bytes<NVB>()))
   CHAIN_ATTR(2, 1); CHAIN_ATTR(4, 1); CHAIN_ATTR(8, 1); CHAIN_ATTR(2, 4); CHAIN_ATTR(4, 4); CHAIN_ATTR(8, 4);
@@ -302,8 +338,8 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
   const size_t smem = std::min<size_t>(pass_smem_bytes(v.KP, nw) + (size_t)h->opt.pass_lds_pad_kb * 1024, kMaxLds);
   // timed mode: the start/stop events are attached to the dispatch itself (hipExtLaunchKernelGGL), so
   // the elapsed time is the kernel's own begin->end, the same quantity rocprofv3 --kernel-trace reports
-  const bool timed = h->opt.time_kernels && h->ev_used + 2 <= h->ev.size();
-  hipEvent_t ev0 = timed ? h->ev[h->ev_used] : nullptr, ev1 = timed ? h->ev[h->ev_used + 1] : nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  const bool timed = take_events(h, xg ? RESNMTF_TIMED_XG : RESNMTF_TIMED_XTF, &ev0, &ev1);
   if (v.half) {       // fp16 image of X: the run-time scale (set at upload) is taken out in the slab store
     a.out_scale = v.u16 ? 1.f / v.xscale : 1.f / (v.xscale * RESNMTF_B16_SCALE);
     // wave-steps per trip: 4 for fp16; 2 for the 16-bit integers (their widening to f32 wants the registers: c2 26.5 k
@@ -324,10 +360,6 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
     }
 #undef LAUNCH_HALF_U
 #undef LAUNCH_HALF
-    if (timed) {
-      h->ev_kind[h->ev_used / 2] = xg ? 0 : 1;
-      h->ev_used += 2;
-    }
     return;
   }
 #define LAUNCH_PASS_B(NTV, NWV, UV, XG, MA, SP)                                                                              \
@@ -352,10 +384,6 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
 #undef LAUNCH_PASS
 #undef LAUNCH_PASS_M
 #undef LAUNCH_PASS_B
-  if (timed) {
-    h->ev_kind[h->ev_used / 2] = xg ? 0 : 1;
-    h->ev_used += 2;
-  }
 }
 
 // a streaming pass without a k x k job (SVD initialisation): mode A kernel, workgroup 0 idles
@@ -428,7 +456,7 @@ void launch_update(resnmtf_handle* h, const ViewState& v, int kind, bool check_d
 template <int NVB>
 WideChainArgs<NVB> narrow_wchain(const WideChainArgs<8>& c) {
   WideChainArgs<NVB> a{};
-  a.len = c.len; a.k = c.k; a.n_views = c.n_views; a.ngroups = c.ngroups; a.own = c.own;
+  a.len = c.len; a.k = c.k; a.n_views = c.n_views; a.ngroups = c.ngroups; a.own = c.own; a.n_self = c.n_self; a.O32 = c.O32; a.o32_stride = c.o32_stride;
   a.W32 = c.W32; a.Wk = c.Wk; a.T32 = c.T32; a.ld32 = c.ld32; a.ctl = c.ctl; a.check_done = c.check_done; a.restricted = c.restricted;
   for (int v = 0; v < NVB; ++v) {
     a.W[v] = c.W[v]; a.U[v] = c.U[v]; a.Ma[v] = c.Ma[v]; a.Md[v] = c.Md[v]; a.lm[v] = c.lm[v];
@@ -437,22 +465,32 @@ WideChainArgs<NVB> narrow_wchain(const WideChainArgs<8>& c) {
   }
   return a;
 }
-// k = 32 / 64: update_f (g == 0) or update_g (g == 1) of every view in one launch
-void launch_wide_chain(resnmtf_handle* h, int g, bool checked) {
-  WideChainArgs<8>& c = h->wchain[g];
+// update_f (g == 0) or update_g (g == 1) of every view in one launch (wide_chain_kernel): the replicated chains (all rows,
+// k > 16) or -- sliced -- this rank's row / column slice of them (any k)
+void launch_wide_chain(resnmtf_handle* h, int g, bool checked, bool sliced = false) {
+  WideChainArgs<8>& c = sliced ? h->schain[g] : h->wchain[g];
   c.check_done = checked ? 1 : 0;
   const int KP = h->views[0].KP;
   const size_t smem = wide_chain_smem_bytes(KP);
-  const dim3 grid(h->wchain_grid[g]), block(16 * KP);
+  const int ngrid = sliced ? h->schain_grid[g] : h->wchain_grid[g];
+  if (ngrid < 1) return;                                   // (an empty slice)
+  const dim3 grid(ngrid), block(16 * KP);
+  const int kind = g == 0 ? RESNMTF_TIMED_F_CHAIN : RESNMTF_TIMED_G_CHAIN;
 #define WCHAIN(KPV, NVBV, ARGS) do { \
-    if (g == 0) hipLaunchKernelGGL((wide_chain_kernel<KPV, false, NVBV>), grid, block, smem, h->stream, ARGS); \
-    else hipLaunchKernelGGL((wide_chain_kernel<KPV, true, NVBV>), grid, block, smem, h->stream, ARGS); } while (0)
+    if (sliced) { if (g == 0) LAUNCH_TIMED(h, kind, (wide_chain_kernel<KPV, false, NVBV, true>), grid, block, smem, ARGS); \
+                  else LAUNCH_TIMED(h, kind, (wide_chain_kernel<KPV, true, NVBV, true>), grid, block, smem, ARGS); } \
+    else if (KPV >= 32) { if (g == 0) LAUNCH_TIMED(h, kind, (wide_chain_kernel<(KPV >= 32 ? KPV : 32), false, NVBV>), grid, block, smem, ARGS); \
+                          else LAUNCH_TIMED(h, kind, (wide_chain_kernel<(KPV >= 32 ? KPV : 32), true, NVBV>), grid, block, smem, ARGS); } } while (0)
+#define WCHAIN_K(NVBV, ARGS) do { \
+    switch (KP) { case 16: WCHAIN(16, NVBV, ARGS); break; case 32: WCHAIN(32, NVBV, ARGS); break; \
+                  case 48: WCHAIN(48, NVBV, ARGS); break; default: WCHAIN(64, NVBV, ARGS); break; } } while (0)
   if (c.n_views <= 4) {
     WideChainArgs<4> a = narrow_wchain<4>(c);
-    if (KP == 32) WCHAIN(32, 4, a); else WCHAIN(64, 4, a);
+    WCHAIN_K(4, a);
   } else {
-    if (KP == 32) WCHAIN(32, 8, c); else WCHAIN(64, 8, c);
+    WCHAIN_K(8, c);
   }
+#undef WCHAIN_K
 #undef WCHAIN
 }
 
@@ -465,8 +503,8 @@ void enqueue_phase_f_all(resnmtf_handle* h, bool checked = false) {
     bool one_slab = true;
     for (int v = 0; v < h->chain_views; ++v) one_slab = one_slab && h->chain.nsplit[v] == 1;
 #define LAUNCH_CHAIN(NVB, ARGS)                                                                                         \
-    if (one_slab) hipLaunchKernelGGL((f_chain_kernel<NVB, 1>), dim3(h->chain_blocks), dim3(512), smem, h->stream, ARGS);  \
-    else hipLaunchKernelGGL((f_chain_kernel<NVB, 4>), dim3(h->chain_blocks), dim3(512), smem, h->stream, ARGS)
+    if (one_slab) LAUNCH_TIMED(h, RESNMTF_TIMED_F_CHAIN, (f_chain_kernel<NVB, 1>), dim3(h->chain_blocks), dim3(512), smem, ARGS);  \
+    else LAUNCH_TIMED(h, RESNMTF_TIMED_F_CHAIN, (f_chain_kernel<NVB, 4>), dim3(h->chain_blocks), dim3(512), smem, ARGS)
     if (h->chain_views <= 2) {
       ChainArgs<2> a = narrow_chain<2>(h->chain);
       LAUNCH_CHAIN(2, a);
@@ -490,19 +528,47 @@ void enqueue_phase_f(resnmtf_handle* h, const ViewState& v, bool checked) { laun
 void launch_fold(resnmtf_handle* h, const ViewState& v) {
   if (!v.Usum) return;
   const int quads = v.n_pad * v.KP / 4;
-  hipLaunchKernelGGL(slab_fold_kernel, dim3(ceil_div(quads, 256)), dim3(256), 0, h->stream, v.Pxg, v.nsplit_xg, quads, v.Usum);
+  LAUNCH_TIMED(h, RESNMTF_TIMED_PACK, slab_fold_kernel, dim3(ceil_div(quads, 256)), dim3(256), 0, v.Pxg, v.nsplit_xg, quads, v.Usum);
 }
 void launch_fold_t(resnmtf_handle* h, const ViewState& v) {
   if (!v.Tsum) return;
   const int quads = v.m_pad * v.KP / 4;
-  hipLaunchKernelGGL(slab_fold_kernel, dim3(ceil_div(quads, 256)), dim3(256), 0, h->stream, v.Pxtf, v.nsplit_xtf, quads, v.Tsum);
+  LAUNCH_TIMED(h, RESNMTF_TIMED_PACK, slab_fold_kernel, dim3(ceil_div(quads, 256)), dim3(256), 0, v.Pxtf, v.nsplit_xtf, quads, v.Tsum);
+}
+// slice_chains: the own view's pass result, folded and cut into the V chunks of the next all-to-all (slice_pack_kernel)
+void launch_slice_pack(resnmtf_handle* h, const ViewState& v, bool xg, bool checked) {
+  SlicePackArgs a{};
+  a.P = xg ? v.Pxg : v.Pxtf; a.nsplit = xg ? v.nsplit_xg : v.nsplit_xtf; a.rows_pad = xg ? v.n_pad : v.m_pad;
+  a.KP = v.KP; a.NT = v.NT;
+  a.rows_per_slice = xg ? h->sl_rows : h->sl_cols; a.n_slices = h->opt.slice_count;
+  a.out = xg ? h->u_send : h->t_send; a.chunk_bytes = xg ? h->u_chunk : h->t_chunk;
+  if (!xg) { a.tail[0] = v.Ma_G; a.tail[1] = v.Md_G; a.tail_count = v.k * v.k; a.T32 = v.T32; a.ld32 = 64; }
+  a.ctl = h->ctl; a.check_done = checked ? 1 : 0;
+  const size_t quads = (size_t)a.n_slices * a.rows_per_slice * (a.KP / 4);
+  LAUNCH_TIMED(h, RESNMTF_TIMED_PACK, slice_pack_kernel, dim3((unsigned)std::min<size_t>((quads + 255) / 256, 65535)), dim3(256), 0, a);
+}
+// slice_chains: the own view's new F (g == 0) / G (g == 1) rows, as received, -> the operand copies of the next pass
+void launch_slice_unpack(resnmtf_handle* h, const ViewState& v, int g, bool checked) {
+  SliceUnpackArgs a{};
+  a.in = g == 0 ? h->f_recv : h->g_recv; a.len = g == 0 ? v.n : v.m; a.k = v.k;
+  a.W32 = g == 0 ? v.F32 : v.G32; a.ld32 = 64; a.Wk = g == 0 ? v.Fk : v.Gk;
+  a.ctl = h->ctl; a.check_done = checked ? 1 : 0;
+  const dim3 grid(ceil_div(a.len, 32)), block(256);
+  switch (v.KP) {
+    case 16: LAUNCH_TIMED(h, RESNMTF_TIMED_PACK, slice_unpack_kernel<16>, grid, block, 0, a); break;
+    case 32: LAUNCH_TIMED(h, RESNMTF_TIMED_PACK, slice_unpack_kernel<32>, grid, block, 0, a); break;
+    case 48: LAUNCH_TIMED(h, RESNMTF_TIMED_PACK, slice_unpack_kernel<48>, grid, block, 0, a); break;
+    default: LAUNCH_TIMED(h, RESNMTF_TIMED_PACK, slice_unpack_kernel<64>, grid, block, 0, a); break;
+  }
 }
 // replicate_gs: the second half of the k x k job of EVERY view (update_s chain, update_lm, error, F coefficients)
-int launch_s_chain(resnmtf_handle* h, int sweep) {
+int launch_s_chain(resnmtf_handle* h, bool checked) {
   SChainArgs a{};
   const int V = h->V;
   const ViewState& v0 = h->views[0];
-  a.k = v0.k; a.n_views = V; a.sweep = sweep;
+  a.k = v0.k; a.n_views = V;
+  a.view_sweep = h->view_sweep; a.ticket = h->view_sweep + V;
+  a.tol = h->phase_tol; a.check_done = checked ? 1 : 0;
   a.sblocks = h->sblk_base; a.sblock_stride = h->sblk_step;
   double sum_xi = 0.0;
   for (double x : h->xi) sum_xi += x;
@@ -522,9 +588,9 @@ int launch_s_chain(resnmtf_handle* h, int sweep) {
   a.ctl = h->ctl; a.ctl_host = h->ctl_host_dev;
   const size_t smem = kk_smem_bytes(v0.KP, 16);
 #define S_CHAIN(KPV) do { \
-    if (V <= 4) hipLaunchKernelGGL((s_chain_kernel<KPV, 4>), dim3(V), dim3(s_chain_threads(KPV)), smem, h->stream, a); \
-    else if (V <= 8) hipLaunchKernelGGL((s_chain_kernel<KPV, 8>), dim3(V), dim3(s_chain_threads(KPV)), smem, h->stream, a); \
-    else hipLaunchKernelGGL((s_chain_kernel<KPV, RESNMTF_MAX_COUPLE + 1>), dim3(V), dim3(s_chain_threads(KPV)), smem, h->stream, a); } while (0)
+    if (V <= 4) LAUNCH_TIMED(h, RESNMTF_TIMED_S_CHAIN, (s_chain_kernel<KPV, 4>), dim3(V), dim3(s_chain_threads(KPV)), smem, a); \
+    else if (V <= 8) LAUNCH_TIMED(h, RESNMTF_TIMED_S_CHAIN, (s_chain_kernel<KPV, 8>), dim3(V), dim3(s_chain_threads(KPV)), smem, a); \
+    else LAUNCH_TIMED(h, RESNMTF_TIMED_S_CHAIN, (s_chain_kernel<KPV, RESNMTF_MAX_COUPLE + 1>), dim3(V), dim3(s_chain_threads(KPV)), smem, a); } while (0)
   switch (v0.NT) {
     case 1: S_CHAIN(16); break;
     case 2: S_CHAIN(32); break;
@@ -546,6 +612,7 @@ void enqueue_prologue(resnmtf_handle* h, const ViewState& v) {
   if (v.kk_mode == 0) launch_update(h, v, 2, false);
   launch_pass(h, v, true, 0, -1.0, false);
   launch_fold(h, v);
+  if (h->sliced) launch_slice_pack(h, v, true, false);
 }
 
 void enqueue_sweep(resnmtf_handle* h, double tol) {
@@ -619,8 +686,10 @@ int flush_timing(resnmtf_handle* h) {
   for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
     float ms = 0.f;
     HIP_TRY(h, hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
-    if (h->ev_kind[i / 2] == 0) { h->timing.xg_ms_total += ms; h->timing.xg_launches++; }
-    else { h->timing.xtf_ms_total += ms; h->timing.xtf_launches++; }
+    const int kind = h->ev_kind[i / 2];
+    if (kind == RESNMTF_TIMED_XG) { h->timing.xg_ms_total += ms; h->timing.xg_launches++; }
+    else if (kind == RESNMTF_TIMED_XTF) { h->timing.xtf_ms_total += ms; h->timing.xtf_launches++; }
+    if (kind >= 0 && kind < RESNMTF_TIMED_KINDS) { h->ktime_ms[kind] += ms; h->klaunch[kind]++; }
   }
   h->ev_used = 0;
   return RESNMTF_OK;
@@ -848,6 +917,21 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     if (opts->struct_size != (int)sizeof(resnmtf_options)) { g_create_error = "options struct_size mismatch"; return RESNMTF_ERR_INVALID; }
     o = *opts;
   }
+  if (o.bf16_split == 1) { g_create_error = "bf16_split = 1 (the two-piece form) is retired: use 0 (three pieces, f32-grade) or 2 (f32 MFMA)"; return RESNMTF_ERR_INVALID; }
+  if (o.slice_chains) {
+    const char* why = nullptr;
+    if (!o.replicate_f || !o.replicate_gs) why = "slice_chains needs replicate_f and replicate_gs";
+    else if (o.slice_count != n_views || n_views < 1 || n_views > 8) why = "slice_chains needs slice_count = number of views <= 8";
+    else if (o.slice_index < 0 || o.slice_index >= o.slice_count) why = "slice_index out of range";
+    else if (o.x_half != 0 || o.kk_mode == 1) why = "slice_chains uses the f32 images and hand-off mode B";
+    else if (!owned) why = "slice_chains needs exactly one owned view (view index = slice_index)";
+    else
+      for (int v = 0; v < n_views && !why; ++v) {
+        if (n_rows[v] != n_rows[0] || n_cols[v] != n_cols[0] || k[v] != k[0]) why = "slice_chains needs equal shapes and k in all views";
+        else if ((owned[v] != 0) != (v == o.slice_index)) why = "slice_chains needs exactly one owned view (view index = slice_index)";
+      }
+    if (why) { g_create_error = why; return RESNMTF_ERR_INVALID; }
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
     g_create_error = "no HIP device available (this library has no CPU fallback)";
@@ -915,7 +999,7 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
   // that produces U) is appended to its F block, so that ONE all-gather after the X.G pass moves both -- two collectives per
   // sweep between dependent steps instead of three
   size_t sblk_tail_bytes = 0;
-  if (o.replicate_f && o.replicate_gs) {
+  if (o.replicate_f && o.replicate_gs && !o.slice_chains) {      // (sliced chains: the S blocks travel on their own, beside the U slices)
     bool equal = true;
     for (const auto& vs : h->views) equal = equal && fblk_size(vs) == fblk_size(h->views[0]) && vs.k == h->views[0].k;
     if (equal) {
@@ -947,6 +1031,25 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
       if ((e = dev_alloc_zero(&h->sblk_arena, h->sblk_stride * n_views)) != hipSuccess) return bail(e, "hipMalloc S exchange blocks");
       h->sblk_base = h->sblk_arena; h->sblk_step = h->sblk_stride;
     }
+    if ((e = dev_alloc_zero(&h->view_sweep, (size_t)n_views + 1)) != hipSuccess) return bail(e, "hipMalloc view_sweep");
+  }
+  if (o.slice_chains) {
+    const ViewState& v0 = h->views[0];
+    const int V = n_views;
+    h->sliced = true;
+    h->sl_rows = round_up(ceil_div(v0.n, V), 32); h->sl_cols = round_up(ceil_div(v0.m, V), 32);
+    h->u_chunk = (size_t)h->sl_rows * v0.KP * sizeof(float);
+    h->t_chunk = ((size_t)h->sl_cols * v0.KP * sizeof(float) + 2 * (size_t)v0.k * v0.k * sizeof(double) + 255) / 256 * 256;
+    char** bufs[4] = {&h->u_send, &h->u_recv, &h->t_send, &h->t_recv};
+    for (int b = 0; b < 4; ++b) {
+      const size_t bytes = (b < 2 ? h->u_chunk : h->t_chunk) * V;
+      if ((e = hipMalloc(reinterpret_cast<void**>(bufs[b]), bytes)) != hipSuccess) return bail(e, "hipMalloc slice exchange buffers");
+      if ((e = hipMemset(*bufs[b], 0, bytes)) != hipSuccess) return bail(e, "hipMemset slice exchange buffers");
+    }
+    if ((e = dev_alloc_zero(&h->f_send, (size_t)V * h->sl_rows * v0.KP)) != hipSuccess) return bail(e, "hipMalloc slice exchange buffers");
+    if ((e = dev_alloc_zero(&h->f_recv, (size_t)V * h->sl_rows * v0.KP)) != hipSuccess) return bail(e, "hipMalloc slice exchange buffers");
+    if ((e = dev_alloc_zero(&h->g_send, (size_t)V * h->sl_cols * v0.KP)) != hipSuccess) return bail(e, "hipMalloc slice exchange buffers");
+    if ((e = dev_alloc_zero(&h->g_recv, (size_t)V * h->sl_cols * v0.KP)) != hipSuccess) return bail(e, "hipMalloc slice exchange buffers");
   }
   size_t fblk_off = 0, gblk_off = 0;
   for (int v = 0; v < n_views; ++v) {
@@ -965,7 +1068,7 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     const size_t xbytes = (size_t)vs.n * vs.m * sizeof(float);
     vs.kk_mode = (vs.KP == 16) ? 0 : 1;
     if (o.kk_mode == 1) vs.kk_mode = 0;
-    if (o.kk_mode == 2) vs.kk_mode = 1;
+    if (o.kk_mode == 2 || o.slice_chains) vs.kk_mode = 1;      // (sliced chains: the Gram products come from the received f32 copy)
     // workgroup slots of a pass launch: target_workgroups overrides CUs x resident workgroups per CU
     const int nw_guess = (vs.NT <= 1 && (o.pass_waves == 4 || o.pass_waves == 8 || o.pass_waves == 16)) ? o.pass_waves : 8;
     const int aux_cap = (vs.NT >= 2 && o.bf16_split != 2) ? 16 : 64;
@@ -1107,6 +1210,9 @@ int resnmtf_destroy(resnmtf_handle* h) {
   if (h->fblk_arena) (void)hipFree(h->fblk_arena);
   if (h->gblk_arena) (void)hipFree(h->gblk_arena);
   if (h->sblk_arena) (void)hipFree(h->sblk_arena);
+  for (void* p : {(void*)h->view_sweep, (void*)h->u_send, (void*)h->u_recv, (void*)h->t_send, (void*)h->t_recv, (void*)h->f_send,
+                  (void*)h->f_recv, (void*)h->g_send, (void*)h->g_recv})
+    if (p) (void)hipFree(p);
   if (h->ctl) (void)hipFree(h->ctl);
   if (h->err) (void)hipFree(h->err);
   if (h->err_host) (void)hipHostFree(h->err_host);
@@ -1777,7 +1883,7 @@ static void build_wide_chain(resnmtf_handle* h) {
   const int V = h->V;
   if (V < 2 || V > 8 || h->opt.no_f_chain) return;
   const ViewState& v0 = h->views[0];
-  if (v0.KP != 32 && v0.KP != 64) return;
+  if (v0.KP < 32 || h->sliced) return;
   for (int g = 0; g < 2; ++g) {
     WideChainArgs<8>& a = h->wchain[g];
     a = WideChainArgs<8>{};
@@ -1806,12 +1912,55 @@ static void build_wide_chain(resnmtf_handle* h) {
           if (u.couple[c].W == (g == 0 ? h->views[w].F : h->views[w].G)) { a.cmask[v] |= 1u << w; a.weight[v][w] = u.couple[c].weight; }
     }
     if (!ok) continue;
-    a.len = g == 0 ? v0.n : v0.m; a.k = v0.k; a.n_views = V; a.ngroups = ceil_div(a.len, 32);
+    a.len = g == 0 ? v0.n : v0.m; a.n_self = a.len; a.k = v0.k; a.n_views = V; a.ngroups = ceil_div(a.len, 32);
     a.ctl = h->ctl;
-    // persistent workgroups: one per CU at k = 64 (157 KB of LDS), two at k = 32
+    // persistent workgroups: one per CU at k > 32 (157 KB of LDS at k = 64, 131 KB at 48), two at k = 32
     h->wchain_grid[g] = std::min(a.ngroups, h->n_cu * (v0.KP == 32 ? 2 : 1));
     h->wchain_ok[g] = true;
   }
+}
+
+// slice_chains: RESNMTF_PHASE_SLICE_F / _G -- the chain of every view on this rank's row (column) slice, one launch
+// (wide_chain_kernel on the slice: inputs = the received rows of every view's product, outputs = the fp64 rows kept here and
+// their f32 copies for the owners)
+static int build_slice_chain(resnmtf_handle* h) {
+  const int V = h->V, r = h->opt.slice_index;
+  const ViewState& v0 = h->views[0];
+  for (int g = 0; g < 2; ++g) {
+    WideChainArgs<8>& a = h->schain[g];
+    a = WideChainArgs<8>{};
+    a.own = -1;
+    const int per = g == 0 ? h->sl_rows : h->sl_cols, full = g == 0 ? v0.n : v0.m;
+    const int begin = std::min(r * per, full), len = std::min(per, full - begin);
+    for (int v = 0; v < V; ++v) {
+      const ViewState& vs = h->views[v];
+      const UpdateArgs& u = g == 0 ? vs.argF : vs.argG;
+      for (int c = 0; c < u.n_couple; ++c)
+        if (u.couple[c].map)
+          return h->fail(RESNMTF_ERR_INVALID, "slice_chains: coupled views must share all their rows / columns in the same order (identity maps)");
+      a.W[v] = (g == 0 ? vs.F : vs.G) + (size_t)begin * vs.k;
+      if (g == 0) {
+        a.U[v] = reinterpret_cast<const float*>(h->u_recv + (size_t)v * h->u_chunk);
+        a.Ma[v] = vs.Ma_F; a.Md[v] = vs.Md_F; a.lm[v] = vs.lambda;
+      } else {
+        const char* chunk = h->t_recv + (size_t)v * h->t_chunk;
+        a.U[v] = reinterpret_cast<const float*>(chunk);
+        a.Ma[v] = reinterpret_cast<const double*>(chunk + (size_t)per * vs.KP * sizeof(float)); a.Md[v] = a.Ma[v] + (size_t)vs.k * vs.k;
+        a.lm[v] = vs.mu;
+      }
+      a.sigma[v] = u.sigma;
+      a.n_other[v] = (double)full;
+      if (u.restricted) a.restricted |= 1u << v;
+      for (int c = 0; c < u.n_couple; ++c)
+        for (int w = 0; w < V; ++w)
+          if (u.couple[c].W == (g == 0 ? h->views[w].F : h->views[w].G)) { a.cmask[v] |= 1u << w; a.weight[v][w] = u.couple[c].weight; }
+    }
+    a.O32 = g == 0 ? h->f_send : h->g_send; a.o32_stride = (unsigned)((size_t)per * v0.KP);
+    a.len = len; a.n_self = full; a.k = v0.k; a.n_views = V; a.ngroups = ceil_div(std::max(len, 0), 32);
+    a.ctl = h->ctl;
+    h->schain_grid[g] = std::min(a.ngroups, h->n_cu * (v0.KP <= 32 ? 2 : 1));
+  }
+  return RESNMTF_OK;
 }
 
 // builds the kernel argument blocks (coupling tables included) from the host-side description
@@ -1930,6 +2079,8 @@ static int build_args(resnmtf_handle* h) {
   }
   build_chain(h);
   build_wide_chain(h);
+  if (h->sliced)
+    if (int rc = build_slice_chain(h)) return rc;
   return RESNMTF_OK;
 }
 
@@ -1945,7 +2096,8 @@ int resnmtf_reserve_sweeps(resnmtf_handle* h, int sweeps) {
 // control is reset, in stream order, without a host synchronisation
 static int prepare_impl(resnmtf_handle* h, bool allow_resume, bool keep_ctl = false) {
   if (!h->prepared) {
-    destroy_graphs(h);
+    if (!h->ladder.empty() || !h->exact.empty()) HIP_TRY(h, hipStreamSynchronize(h->stream));   // (a graph may still be executing:
+    destroy_graphs(h);                                                                           //  resnmtf_run returns on a counter)
     if (int rc = build_args(h)) return rc;
     h->prepared = true;
   }
@@ -1957,6 +2109,7 @@ static int prepare_impl(resnmtf_handle* h, bool allow_resume, bool keep_ctl = fa
   h->sweep_base = h->next_base = 0;
   std::memset(h->ctl_host, 0, sizeof(SweepCtl));
   HIP_TRY(h, hipMemsetAsync(h->ctl, 0, sizeof(SweepCtl), h->stream));      // all-zero bytes = SweepCtl{}
+  if (h->view_sweep) HIP_TRY(h, hipMemsetAsync(h->view_sweep, 0, ((size_t)h->V + 1) * sizeof(int), h->stream));
   if (resume) return RESNMTF_OK;
   // run prologue: F coefficients and the first X.G pass of every owned view
   h->resume_ok = false;
@@ -1982,29 +2135,53 @@ int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep) {
     return h->fail(RESNMTF_ERR_STATE, "phase on a view this handle does not own");
   if (phase >= RESNMTF_PHASE_XTF && phase <= RESNMTF_PHASE_S_ALL && !h->opt.replicate_gs)
     return h->fail(RESNMTF_ERR_STATE, "this phase needs a handle created with replicate_gs = 1");
+  if (phase >= RESNMTF_PHASE_SLICE_F && phase <= RESNMTF_PHASE_SLICE_XG && !h->sliced)
+    return h->fail(RESNMTF_ERR_STATE, "this phase needs a handle created with slice_chains = 1");
+  if (h->sliced && phase != RESNMTF_PHASE_S_ALL && !(phase >= RESNMTF_PHASE_SLICE_F && phase <= RESNMTF_PHASE_SLICE_XG))
+    return h->fail(RESNMTF_ERR_STATE, "slice_chains: use PHASE_SLICE_F / SLICE_XTF / SLICE_G / SLICE_XG / S_ALL");
+  if ((phase == RESNMTF_PHASE_SLICE_XTF || phase == RESNMTF_PHASE_SLICE_XG) && !vs.owned)
+    return h->fail(RESNMTF_ERR_STATE, "phase on a view this handle does not own");
   if (h->opt.replicate_gs && (phase == RESNMTF_PHASE_G || phase == RESNMTF_PHASE_LOCAL_SWEEP))
     return h->fail(RESNMTF_ERR_STATE, "replicate_gs: use PHASE_XTF / G_ALL / XG / S_ALL instead of PHASE_G");
   if (sweep < 0) return h->fail(RESNMTF_ERR_INVALID, "negative sweep index");
   if (sweep >= h->err_cap) return h->fail(RESNMTF_ERR_STATE, "sweep beyond the reserved error buffer (resnmtf_reserve_sweeps)");
   h->resume_ok = false;
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
+  if (h->opt.time_kernels && h->ev_used + 64 > h->ev.size())
+    if (int rc = flush_timing(h)) return rc;
+  // convergence mode of the phase API (resnmtf_set_stop_tolerance): the replicated S chain runs the stop test, every kernel
+  // of a checked phase leaves at once when the flag is up
+  const double tol = h->opt.replicate_gs ? h->phase_tol : -1.0;
+  const bool checked = tol >= 0.0;
   switch (phase) {
     case RESNMTF_PHASE_F: enqueue_phase_f(h, vs, false); break;
     case RESNMTF_PHASE_G: enqueue_phase_g(h, vs, -1.0, false); break;
     case RESNMTF_PHASE_S: break;   // S is complete behind PHASE_G on the handle's stream
-    case RESNMTF_PHASE_F_ALL: enqueue_phase_f_all(h); break;
+    case RESNMTF_PHASE_F_ALL: enqueue_phase_f_all(h, checked); break;
     case RESNMTF_PHASE_LOCAL_SWEEP:
       if (int rc = launch_local_sweep(h)) return rc;
       break;
-    case RESNMTF_PHASE_XTF: launch_pass(h, vs, false, 1, -1.0, false); launch_fold_t(h, vs); break;
+    case RESNMTF_PHASE_XTF: launch_pass(h, vs, false, 1, tol, checked); launch_fold_t(h, vs); break;
     case RESNMTF_PHASE_G_ALL:
-      if (h->wchain_ok[1]) { launch_wide_chain(h, 1, false); break; }
+      if (h->wchain_ok[1]) { launch_wide_chain(h, 1, checked); break; }
       for (const auto& w : h->views)
-        if (w.owned || w.g_replica) launch_update(h, w, 1, false);
+        if (w.owned || w.g_replica) launch_update(h, w, 1, checked);
       break;
-    case RESNMTF_PHASE_XG: launch_pass(h, vs, true, 1, -1.0, false); launch_fold(h, vs); break;
+    case RESNMTF_PHASE_XG: launch_pass(h, vs, true, 1, tol, checked); launch_fold(h, vs); break;
     case RESNMTF_PHASE_S_ALL:
-      if (int rc = launch_s_chain(h, sweep)) return rc;
+      if (int rc = launch_s_chain(h, checked)) return rc;
+      break;
+    case RESNMTF_PHASE_SLICE_F: launch_wide_chain(h, 0, checked, true); break;
+    case RESNMTF_PHASE_SLICE_XTF:
+      launch_slice_unpack(h, vs, 0, checked);
+      launch_pass(h, vs, false, 1, tol, checked);
+      launch_slice_pack(h, vs, false, checked);
+      break;
+    case RESNMTF_PHASE_SLICE_G: launch_wide_chain(h, 1, checked, true); break;
+    case RESNMTF_PHASE_SLICE_XG:
+      launch_slice_unpack(h, vs, 1, checked);
+      launch_pass(h, vs, true, 1, tol, checked);
+      launch_slice_pack(h, vs, true, checked);
       break;
     default: return h->fail(RESNMTF_ERR_INVALID, "unknown phase");
   }
@@ -2046,7 +2223,10 @@ int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, doubl
   h->resume_ok = false;
   const bool eager = !h->opt.use_graph || h->opt.time_kernels;
   const int batch = std::max(1, h->opt.check_every);
-  if (!eager && h->graph_tol != tol_arg) { destroy_graphs(h); h->graph_tol = tol_arg; }     // graphs are captured per stop test
+  if (!eager && h->graph_tol != tol_arg) {                 // graphs are captured per stop test
+    if (!h->ladder.empty() || !h->exact.empty()) HIP_TRY(h, hipStreamSynchronize(h->stream));   // (the previous run returned on the
+    destroy_graphs(h); h->graph_tol = tol_arg;                                                   //  counter: its graph may still execute)
+  }
   int enq = 0;
   if (!eager && total > 1) {
     // the first sweep goes out as plain launches: its first kernel starts within a few microseconds, where a graph launch
@@ -2064,7 +2244,10 @@ int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, doubl
     for (const auto& g : h->exact)
       if (g.first == rest) ex = g.second;
     if (!ex) {
-      if (h->exact.size() >= 4) { (void)hipGraphExecDestroy(h->exact.front().second); h->exact.erase(h->exact.begin()); }
+      if (h->exact.size() >= 4) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));           // (it may be the graph the previous run is still draining)
+        (void)hipGraphExecDestroy(h->exact.front().second); h->exact.erase(h->exact.begin());
+      }
       if (int rc = capture_graph(h, rest, tol_arg, &ex)) return rc;
       h->exact.emplace_back(rest, ex);
     }
@@ -2099,7 +2282,7 @@ int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, doubl
   }
   HIP_TRY(h, hipGetLastError());
   if (trace) tp[2] = clk::now();
-  if (tol_arg < 0.0 && !h->opt.time_kernels && h->last_owned >= 0) {
+  if (tol_arg < 0.0 && !h->opt.time_kernels && h->last_owned >= 0 && h->opt.wait_mode == 0) {
     // fixed-iteration runs: wait for the sweep counter the LAST k x k job mirrors into pinned host memory (errors are
     // written, and fenced, before it) instead of a stream synchronisation, whose wake-up costs ~10 us of a 0.9 ms run;
     // the stream may still be draining the last launch's workgroups -- every other entry point synchronises it first.
@@ -2112,6 +2295,7 @@ int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, doubl
       const int now = *counter;
       if (now != seen) { seen = now; t_last = clk::now(); }
       else if (std::chrono::duration<double, std::milli>(clk::now() - t_last).count() > 20.0) break;
+      for (int p = 0; p < 16; ++p) __builtin_ia32_pause();     // (back off: the core's sibling thread and the memory bus get air)
     }
     if (seen != want)
       if (int rc = sync_both(h)) return rc;
@@ -2220,8 +2404,70 @@ int resnmtf_factor_device_ptr(resnmtf_handle* h, int v, int which, void** ptr, s
       if (h->sblk_embedded) return h->fail(RESNMTF_ERR_STATE, "the S blocks of this handle sit inside the F blocks (RESNMTF_FACTOR_FBLOCK_ALL moves both)");
       if (!h->sblk_arena) return h->fail(RESNMTF_ERR_STATE, "no S exchange blocks: create the handle with replicate_gs = 1");
       *ptr = h->sblk_arena; *bytes = h->sblk_stride * sizeof(double) * h->V; break;
+    case RESNMTF_FACTOR_U_SEND: case RESNMTF_FACTOR_U_RECV: case RESNMTF_FACTOR_FNEW_SEND: case RESNMTF_FACTOR_FNEW_RECV:
+    case RESNMTF_FACTOR_T_SEND: case RESNMTF_FACTOR_T_RECV: case RESNMTF_FACTOR_GNEW_SEND: case RESNMTF_FACTOR_GNEW_RECV:
+    case RESNMTF_FACTOR_F_SLICE: case RESNMTF_FACTOR_G_SLICE: {
+      if (!h->sliced) return h->fail(RESNMTF_ERR_STATE, "no slice buffers: create the handle with slice_chains = 1");
+      const size_t V = (size_t)h->V;
+      const size_t fbytes = V * h->sl_rows * vs.KP * sizeof(float), gbytes = V * h->sl_cols * vs.KP * sizeof(float);
+      switch (which) {
+        case RESNMTF_FACTOR_U_SEND: *ptr = h->u_send; *bytes = V * h->u_chunk; break;
+        case RESNMTF_FACTOR_U_RECV: *ptr = h->u_recv; *bytes = V * h->u_chunk; break;
+        case RESNMTF_FACTOR_T_SEND: *ptr = h->t_send; *bytes = V * h->t_chunk; break;
+        case RESNMTF_FACTOR_T_RECV: *ptr = h->t_recv; *bytes = V * h->t_chunk; break;
+        case RESNMTF_FACTOR_FNEW_SEND: *ptr = h->f_send; *bytes = fbytes; break;
+        case RESNMTF_FACTOR_FNEW_RECV: *ptr = h->f_recv; *bytes = fbytes; break;
+        case RESNMTF_FACTOR_GNEW_SEND: *ptr = h->g_send; *bytes = gbytes; break;
+        case RESNMTF_FACTOR_GNEW_RECV: *ptr = h->g_recv; *bytes = gbytes; break;
+        default: {
+          const bool f = which == RESNMTF_FACTOR_F_SLICE;
+          const int per = f ? h->sl_rows : h->sl_cols, full = f ? vs.n : vs.m;
+          const int begin = std::min(h->opt.slice_index * per, full), len = std::min(per, full - begin);
+          *ptr = (f ? vs.F : vs.G) + (size_t)begin * vs.k; *bytes = (size_t)len * vs.k * sizeof(double);
+        }
+      }
+      break;
+    }
     default: return h->fail(RESNMTF_ERR_INVALID, "unknown factor selector");
   }
+  return RESNMTF_OK;
+}
+
+int resnmtf_set_stop_tolerance(resnmtf_handle* h, double tol) {
+  if (!h) return RESNMTF_ERR_INVALID;
+  if (tol >= 0.0 && !h->opt.replicate_gs)
+    return h->fail(RESNMTF_ERR_STATE, "the phase API's stop test runs in the replicated S chain (replicate_gs / slice_chains); resnmtf_run has its own");
+  h->phase_tol = tol >= 0.0 ? tol : -1.0;
+  return RESNMTF_OK;
+}
+
+int resnmtf_loop_state(resnmtf_handle* h, int* sweeps_done, int* done, int* stop_sweep) {
+  if (!h) return RESNMTF_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->opt.device_id));
+  if (int rc = sync_both(h)) return rc;
+  SweepCtl c{};
+  HIP_TRY(h, hipMemcpy(&c, h->ctl, sizeof(c), hipMemcpyDeviceToHost));
+  if (sweeps_done) *sweeps_done = c.sweep;
+  if (done) *done = c.done;
+  if (stop_sweep) *stop_sweep = c.stop_sweep;
+  return RESNMTF_OK;
+}
+
+int resnmtf_slice_info(resnmtf_handle* h, int* rows_per_slice, int* cols_per_slice) {
+  if (!h) return RESNMTF_ERR_INVALID;
+  if (!h->sliced) return h->fail(RESNMTF_ERR_STATE, "not a slice_chains handle");
+  if (rows_per_slice) *rows_per_slice = h->sl_rows;
+  if (cols_per_slice) *cols_per_slice = h->sl_cols;
+  return RESNMTF_OK;
+}
+
+int resnmtf_kernel_timings(resnmtf_handle* h, double* ms_total, long long* launches, int reset) {
+  if (!h || !ms_total || !launches) return RESNMTF_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->opt.device_id));
+  if (int rc = flush_timing(h)) return rc;
+  for (int i = 0; i < RESNMTF_TIMED_KINDS; ++i) { ms_total[i] = h->ktime_ms[i]; launches[i] = h->klaunch[i]; }
+  if (reset)
+    for (int i = 0; i < RESNMTF_TIMED_KINDS; ++i) { h->ktime_ms[i] = 0.0; h->klaunch[i] = 0; }
   return RESNMTF_OK;
 }
 

@@ -41,7 +41,8 @@ class Engine:
                  time_kernels: bool = False, pass_waves: int = 0, pass_splits_xg: int = 0,
                  pass_splits_xtf: int = 0, pass_lds_pad_kb: int = 0, update_blocks: int = 0, no_pitch_pad: bool = False,
                  kk_mode: int = 0, bf16_split: int = 0, replicate_f: bool = False, no_f_chain: bool = False,
-                 x_half: int = 0, half_unroll: int = 0, replicate_gs: bool = False):
+                 x_half: int = 0, half_unroll: int = 0, replicate_gs: bool = False, wait_mode: int = 0,
+                 slice_chains: bool = False, slice_index: int = 0, slice_count: int = 0):
         self._lib = _lib.load()
         self.n_views = len(n_rows)
         self.n_rows = [int(x) for x in n_rows]
@@ -69,6 +70,10 @@ class Engine:
         opts.x_half = int(x_half)
         opts.half_unroll = int(half_unroll)
         opts.replicate_gs = 1 if replicate_gs else 0
+        opts.wait_mode = int(wait_mode)
+        opts.slice_chains = 1 if slice_chains else 0
+        opts.slice_index = int(slice_index)
+        opts.slice_count = int(slice_count)
         nr = np.asarray(self.n_rows, dtype=np.int32)
         nc = np.asarray(self.n_cols, dtype=np.int32)
         kk = np.asarray(self.k, dtype=np.int32)
@@ -252,6 +257,28 @@ class Engine:
         rel = C.c_double(0.0)
         self._check(self._lib.resnmtf_view_image_info(self._h, v, C.byref(kind), C.byref(rel)))
         return int(kind.value), float(rel.value)
+
+    def set_stop_tolerance(self, tol: float):
+        """Phase API: ``tol >= 0`` = convergence mode (``R/main.r:50-81``) for the phases enqueued from now on."""
+        self._check(self._lib.resnmtf_set_stop_tolerance(self._h, float(tol)))
+
+    def loop_state(self):
+        """(sweeps closed since prepare, stop flag, sweep count at which it fired) -- synchronises."""
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._check(self._lib.resnmtf_loop_state(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), bool(b.value), int(c.value)
+
+    def slice_info(self):
+        a, b = C.c_int(0), C.c_int(0)
+        self._check(self._lib.resnmtf_slice_info(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def kernel_timings(self, reset: bool = False) -> dict:
+        """time_kernels: {kind: (ms_total, launches)} for the kernels of a view-sharded sweep."""
+        n = len(_lib.TIMED_KINDS)
+        ms = (C.c_double * n)(); cnt = (C.c_longlong * n)()
+        self._check(self._lib.resnmtf_kernel_timings(self._h, ms, cnt, 1 if reset else 0))
+        return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(_lib.TIMED_KINDS)}
 
     def pass_timings(self, reset: bool = False) -> dict:
         t = _lib.PassTiming()

@@ -55,13 +55,40 @@ from typing import Callable, Dict, List, Optional, Sequence
 import numpy as np
 
 from . import naming
-from ._lib import (FACTOR_F, FACTOR_FBLOCK, FACTOR_FBLOCK_ALL, FACTOR_G, FACTOR_GBLOCK, FACTOR_GBLOCK_ALL, FACTOR_S,
-                   FACTOR_SBLOCK, FACTOR_SBLOCK_ALL, PHASE_F, PHASE_F_ALL, PHASE_G, PHASE_G_ALL, PHASE_LOCAL_SWEEP, PHASE_S,
-                   PHASE_S_ALL, PHASE_XG, PHASE_XTF)
+from ._lib import (FACTOR_F, FACTOR_FBLOCK, FACTOR_FBLOCK_ALL, FACTOR_FNEW_RECV, FACTOR_FNEW_SEND, FACTOR_G, FACTOR_GBLOCK,
+                   FACTOR_GBLOCK_ALL, FACTOR_GNEW_RECV, FACTOR_GNEW_SEND, FACTOR_S, FACTOR_SBLOCK, FACTOR_SBLOCK_ALL,
+                   FACTOR_T_RECV, FACTOR_T_SEND, FACTOR_U_RECV, FACTOR_U_SEND, PHASE_F, PHASE_F_ALL, PHASE_G, PHASE_G_ALL,
+                   PHASE_LOCAL_SWEEP, PHASE_S, PHASE_S_ALL, PHASE_SLICE_F, PHASE_SLICE_G, PHASE_SLICE_XG, PHASE_SLICE_XTF,
+                   PHASE_XG, PHASE_XTF)
 from .synth import Problem, planted_view, random_init
 
 _WHICH = {"F": FACTOR_F, "G": FACTOR_G, "S": FACTOR_S, "FBLOCK": FACTOR_FBLOCK, "FBLOCK_ALL": FACTOR_FBLOCK_ALL,
-          "GBLOCK": FACTOR_GBLOCK, "GBLOCK_ALL": FACTOR_GBLOCK_ALL, "SBLOCK": FACTOR_SBLOCK, "SBLOCK_ALL": FACTOR_SBLOCK_ALL}
+          "GBLOCK": FACTOR_GBLOCK, "GBLOCK_ALL": FACTOR_GBLOCK_ALL, "SBLOCK": FACTOR_SBLOCK, "SBLOCK_ALL": FACTOR_SBLOCK_ALL,
+          "U_SEND": FACTOR_U_SEND, "U_RECV": FACTOR_U_RECV, "FNEW_SEND": FACTOR_FNEW_SEND, "FNEW_RECV": FACTOR_FNEW_RECV,
+          "T_SEND": FACTOR_T_SEND, "T_RECV": FACTOR_T_RECV, "GNEW_SEND": FACTOR_GNEW_SEND, "GNEW_RECV": FACTOR_GNEW_RECV}
+
+
+def sliceable(prob: Problem, owner_of: Sequence[int], world: int) -> bool:
+    """Can the F / G chains of ``prob`` be ROW-SLICED over the ranks (``resnmtf_options.slice_chains``)?  One view per rank
+    (view v on rank v, at most 8), equal shapes and k, and every phi- (psi-) coupled pair of views shares ALL its rows
+    (columns) in the same order -- the reference's auto-naming (``R/utils.r:482-491``) and every BASELINE configuration:
+    ``star_prod_relevant`` (``R/utils.r:63-78``) then couples row r of view v with row r of view i and nothing else."""
+    n_v = len(prob.init_f)
+    if n_v != world or n_v > 8 or list(owner_of) != list(range(world)):
+        return False
+    shapes = {(f.shape[0], g.shape[0], f.shape[1]) for f, g in zip(prob.init_f, prob.init_g)}
+    if len(shapes) != 1:
+        return False
+    phi, psi = np.asarray(prob.phi), np.asarray(prob.psi)
+    for v in range(n_v):
+        for w in range(n_v):
+            if v == w:
+                continue
+            if phi[v, w] != 0 and list(prob.row_names[v]) != list(prob.row_names[w]):
+                return False
+            if psi[v, w] != 0 and list(prob.col_names[v]) != list(prob.col_names[w]):
+                return False
+    return True
 
 
 def exchange_plan(n_views: int, owner_of: Sequence[int], phi, xi, psi, row_shared, col_shared) -> List[Dict[str, bool]]:
@@ -118,6 +145,19 @@ class _CudaBlob:
 class HipEngineAdapter:
     """What the driver needs from an engine, on top of ``resnmtf_amd.engine.Engine``."""
     supports_replicated_gs = True
+    supports_sliced = True
+
+    def slice_info(self):
+        return self.e.slice_info()
+
+    def set_stop_tolerance(self, tol):
+        self.e.set_stop_tolerance(tol)
+
+    def loop_state(self):
+        return self.e.loop_state()
+
+    def kernel_timings(self, reset=False):
+        return self.e.kernel_timings(reset)
 
     def __init__(self, engine):
         self.e = engine
@@ -240,6 +280,7 @@ class ShardedSweep:
         self.group = group
         self.rank, self.world = rank, world
         self.n_views = len(prob.init_f)
+        self._k = int(prob.init_f[0].shape[1])
         self.owner_of = list(owner_of)
         if len(self.owner_of) != self.n_views or any(o < 0 or o >= world for o in self.owner_of):
             raise ValueError("owner_of must give a valid rank for every view")
@@ -259,10 +300,21 @@ class ShardedSweep:
         # then run at the same time, where ordered broadcasts of G_v / S_v would serialise whole ranks behind each other
         # (G_v' needs G_w' of every w < v, R/update_steps.r:195-204; S likewise, :231-237)
         want_gs = engine_opts.pop("replicate_gs", None)
+        want_slice = engine_opts.pop("slice_chains", None)
+        self._overlap_u = bool(engine_opts.pop("overlap_u", True))
         gs_coupled = any(p["G"] or p["S"] for p in self.plan)
         k_all = [f.shape[1] for f in prob.init_f]
         can_gs = (bool(replicate_f) and self.owner_of == list(range(world)) and len(set(k_all)) == 1 and self.n_views == world)
         self.replicate_gs = bool(can_gs and (gs_coupled if want_gs is None else want_gs))
+        # Row-sliced chains instead of replicated ones (one view's worth of chain work per rank instead of V views'): needs the
+        # layout of `sliceable`; chosen by default above k = 16, where a chain step costs more than the two extra exchanges
+        # (the k <= 16 chains of c2-sized views are a few microseconds: one all-gather per sweep beats four all-to-alls)
+        can_slice = bool(self.replicate_gs and sliceable(prob, self.owner_of, world) and
+                         (engine is None or getattr(engine, "supports_sliced", False)))
+        self.sliced = bool(can_slice and ((k_all[0] > 16) if want_slice is None else want_slice))
+        if want_slice and not self.sliced:
+            raise ValueError("slice_chains needs one view per rank (<= 8), equal shapes and k, coupled views sharing all their "
+                             "rows / columns in the same order, and coupling that calls for the replicated-chains layout")
         if self.replicate_gs:
             self.replicated = [True] * self.n_views
             for v in range(self.n_views):
@@ -287,6 +339,8 @@ class ShardedSweep:
             torch.cuda.set_device(device_index)
             self._tstream = torch.cuda.Stream(device=device_index)
             self._xstream = self._tstream if self._serial else torch.cuda.Stream(device=device_index)
+            if self.sliced:
+                engine_opts = dict(engine_opts, slice_chains=True, slice_index=rank, slice_count=world)
             self.engine = make_hip_engine(prob, self.owned, device_index, self._tstream.cuda_stream,
                                           replicate_f=any(self.replicated), replicate_gs=self.replicate_gs, **engine_opts)
         self.sweeps_done = 0
@@ -297,6 +351,19 @@ class ShardedSweep:
         if self.replicate_gs and self._tstream is not None:       # collectives between dependent steps: one stream
             self._serial = True
             self._xstream = self._tstream
+        if self.sliced and engine_factory is not None and not getattr(self.engine, "supports_sliced", False):
+            raise ValueError("slice_chains needs an engine with the slice phases")
+        # sliced chains: the U slices of a sweep travel beside the S-block gather and the S chain (nothing but the NEXT sweep's
+        # F chain reads them) -- on a second stream and a second communicator, ordered by events (RCCL only; gloo is blocking)
+        self._group_u = None
+        self._ustream = None
+        self._ev_u = self._ev_xg = None
+        self._collected = True
+        if self.sliced and self._tstream is not None and self._overlap_u and dist.get_backend(group) == "nccl":
+            import torch
+            self._group_u = dist.new_group(ranks=list(range(world)), backend="nccl")      # collective: every rank gets here
+            self._ustream = torch.cuda.Stream(device=device_index)
+            self._ev_u, self._ev_xg = torch.cuda.Event(), torch.cuda.Event()
         # S blocks inside the F blocks (the HIP library with equal-shaped views): two collectives per sweep instead of three
         self._s_in_f = bool(self.replicate_gs and getattr(self.engine, "sblock_in_fblock", False))
         # all-gather layout: the exchange sits between two dependent steps of the sweep (nothing to overlap it
@@ -326,6 +393,8 @@ class ShardedSweep:
     @property
     def collectives_per_sweep(self) -> int:
         """Collectives between dependent steps of one sweep in the replicated-chains layouts (0: ordered broadcasts)."""
+        if self.sliced:          # F rows back, T slices, G rows back, S blocks (+ the U slices beside the S chain when overlapped)
+            return 4 if self._group_u is not None else 5
         if self.replicate_gs:
             return 2 if self._s_in_f else 3
         return 1 if self._allgather_blocks else 0
@@ -395,6 +464,77 @@ class ShardedSweep:
             self.engine.phase(r, PHASE_S_ALL, t)
             self._gather_blocks("FBLOCK")
 
+    def _all_to_all(self, recv, send, group=None):
+        """Chunk c of ``send`` to rank c, chunk r of ``recv`` from rank r (equal chunks): RCCL all-to-all on device tensors;
+        CPU tensors (stand-in engine) go through gloo as they are; device tensors over gloo (ranks sharing one GPU in the
+        tests and rehearsals) are staged through the host."""
+        group = self.group if group is None else group
+        if not recv.is_cuda or self.dist.get_backend(group) == "nccl":
+            self.dist.all_to_all_single(recv, send, group=group)
+            return
+        host_in = send.cpu()                      # (blocking copies on the current = compute stream)
+        host_out = host_in.new_empty(host_in.shape)
+        self.dist.all_to_all_single(host_out, host_in, group=group)
+        recv.copy_(host_out)
+
+    def _exchange(self, kind: str, group=None):
+        self._all_to_all(self.engine.factor_tensor(0, kind + "_RECV"), self.engine.factor_tensor(0, kind + "_SEND"), group)
+
+    def _exchange_u(self):
+        """The U slices of the X.G' passes just enqueued -> the slice holders.  Only the next sweep's F chain reads them, so
+        with RCCL they travel on their own stream and communicator beside the S-block gather and the S chain."""
+        if self._group_u is None:
+            self._exchange("U")
+            return
+        import torch
+        self._ev_xg.record(self._tstream)
+        self._ustream.wait_event(self._ev_xg)                 # the pack of the pass that produced them
+        with torch.cuda.stream(self._ustream):
+            self._exchange("U", self._group_u)
+        self._ev_u.record(self._ustream)
+
+    def _sweep_sliced(self, t: int):
+        """One sweep with ROW-SLICED F and G chains and the replicated S chain (R/update_steps.r:282-314 in the reference's
+        order; star_prod_relevant is row-local, R/utils.r:67-73):
+            F chain of every view on my row slice -> [new F rows to their owners] -> operand copies, Xt.F pass of the own view
+            -> [T column slices + G coefficients] -> G chain of every view on my column slice -> [new G rows to their owners]
+            -> operand copies, X.G' pass of the own view + first half of its k x k job
+            -> [S blocks] -> S chain, lambda, mu, error, F coefficients of every view    ||   [U row slices]  (beside it)"""
+        r, e = self.rank, self.engine
+        if self._group_u is not None:
+            self._tstream.wait_event(self._ev_u)             # this sweep's F chain reads the U slices
+        e.phase(r, PHASE_SLICE_F, t)
+        self._exchange("FNEW")
+        e.phase(r, PHASE_SLICE_XTF, t)
+        self._exchange("T")
+        e.phase(r, PHASE_SLICE_G, t)
+        self._exchange("GNEW")
+        e.phase(r, PHASE_SLICE_XG, t)
+        self._exchange_u()
+        self._gather_blocks("SBLOCK")
+        e.phase(r, PHASE_S_ALL, t)
+
+    def collect(self):
+        """Sliced chains: during the sweeps rank r keeps rows (columns) slice r of EVERY view's fp64 F (G) current and nothing
+        else; this hands every slice to the rank that owns the view (one all-to-all per factor), after which the owner's
+        F and G are whole.  Called by the result accessors; cheap (2 x n k doubles per rank)."""
+        if not self.sliced or self._collected:
+            return
+        import torch
+        per = dict(zip(("F", "G"), self.engine.slice_info()))
+        k = self._k
+        for kind in ("F", "G"):
+            full = [self.engine.factor_tensor(v, kind) for v in range(self.n_views)]
+            n_el, chunk = full[0].numel(), per[kind] * k
+            send = torch.zeros(self.n_views * chunk, dtype=full[0].dtype, device=full[0].device)
+            lo, hi = min(self.rank * chunk, n_el), min((self.rank + 1) * chunk, n_el)
+            for v in range(self.n_views):
+                send[v * chunk:v * chunk + (hi - lo)] = full[v][lo:hi]
+            recv = torch.empty_like(send)
+            self._all_to_all(recv, send)
+            full[self.rank].copy_(recv[:n_el])
+        self._collected = True
+
     def _bcast(self, v: int, which: str):
         t = self.engine.factor_tensor(v, which)
         if self._tstream is None:                      # CPU stand-in engine: plain blocking broadcast
@@ -459,23 +599,53 @@ class ShardedSweep:
             raise RuntimeError("reserve() must precede the first run()")
         self._want_reserved = int(total_sweeps)
 
-    def run(self, n_sweeps: int, graph_chunk: int = 0):
-        """``n_sweeps`` more sweeps (fixed-iteration mode, R/main.r:83-108).
+    def run(self, n_sweeps: Optional[int], graph_chunk: int = 0, tol: float = 1.0e-6, max_iters: int = 100000,
+            check_every: int = 16) -> int:
+        """``n_sweeps`` more sweeps (fixed-iteration mode, R/main.r:83-108), or -- ``n_sweeps=None``, layouts with the
+        replicated S chain -- the reference's default loop (R/main.r:50-81): sweeps until ``|mean_err_t - mean_err_{t-1}| <=
+        tol`` (``max_iters`` is a guard the reference lacks).  The S chain of every rank holds the full per-view error table
+        and evaluates the test on the device, on identical bytes: every rank stops on the same sweep without a collective; the
+        host looks at the flag every ``check_every`` sweeps (the sweeps enqueued after it fired return at once).  Returns the
+        number of sweeps executed by this call.
 
         ``graph_chunk`` > 0 (one-stream layouts on RCCL only, OFF by default): ``graph_chunk`` sweeps -- the library's
         launches and the collectives between them -- are captured once in a ``torch.cuda.CUDAGraph`` and replayed.
         Measured with one rank: 46.5 instead of 54.1 us per sweep; not yet validated on several GPUs, hence opt-in."""
+        if n_sweeps is None:
+            return self._run_to_convergence(float(tol), int(max_iters), max(1, int(check_every)))
         if n_sweeps <= 0:
-            return
+            return 0
         if self._tstream is not None:
             import torch
             with torch.cuda.stream(self._xstream):      # one context switch per call, not one per broadcast
-                if graph_chunk > 0 and self._xstream is self._tstream and n_sweeps >= graph_chunk:
-                    n_sweeps = self._run_graphed(n_sweeps, int(graph_chunk))
-                if n_sweeps > 0:
-                    self._run(n_sweeps)
-            return
+                left = n_sweeps
+                if graph_chunk > 0 and self._xstream is self._tstream and n_sweeps >= graph_chunk and not self.sliced:
+                    left = self._run_graphed(n_sweeps, int(graph_chunk))
+                if left > 0:
+                    self._run(left)
+            return n_sweeps
         self._run(n_sweeps)
+        return n_sweeps
+
+    def _run_to_convergence(self, tol: float, max_iters: int, check_every: int) -> int:
+        if not self.replicate_gs:
+            raise ValueError("convergence mode of the view-sharded path needs the replicated S chain (replicate_gs / slice_chains)")
+        if not self._prepared:
+            self.reserve(max(getattr(self, "_want_reserved", 0), max_iters))
+        self.engine.set_stop_tolerance(tol)
+        start = self.sweeps_done
+        try:
+            while self.sweeps_done - start < max_iters:
+                todo = min(check_every, max_iters - (self.sweeps_done - start))
+                before = self.sweeps_done
+                self.run(todo)
+                _, done, stop_sweep = self.engine.loop_state()      # synchronises; identical on every rank
+                if done:
+                    self.sweeps_done = max(before, min(self.sweeps_done, stop_sweep))
+                    break
+        finally:
+            self.engine.set_stop_tolerance(-1.0)
+        return self.sweeps_done - start
 
     def _run_graphed(self, n_sweeps: int, chunk: int) -> int:
         """Replays of a captured chunk; returns the sweeps left for the eager loop."""
@@ -509,6 +679,8 @@ class ShardedSweep:
             if self.replicate_gs:         # F blocks (U, coefficients, lambda) and G blocks (mu of every view)
                 self._gather_blocks("FBLOCK")
                 self._gather_blocks("GBLOCK")
+                if self.sliced:           # ... and every view's U rows of my slice (the run prologue packed them)
+                    self._exchange_u()
             elif any(self.replicated):    # the run prologue filled the owners' blocks: hand them round once
                 if self._tstream is not None and self._xstream is not self._tstream:
                     self._ev_g = self._next_event()
@@ -524,6 +696,11 @@ class ShardedSweep:
         two_streams = self._tstream is not None and self._xstream is not self._tstream
         for _ in range(n_sweeps):
             t = self.sweeps_done
+            if self.sliced:
+                self._sweep_sliced(t)
+                self._collected = False
+                self.sweeps_done += 1
+                continue
             if self.replicate_gs:
                 self._sweep_replicated_gs(t)
                 self.sweeps_done += 1
@@ -575,6 +752,7 @@ class ShardedSweep:
 
     def gather_results(self, dst: int = 0):
         """normalisation_check + binary clusters of every view, collected on rank ``dst``."""
+        self.collect()
         mine = {v: self.engine.finalise(v) for v in range(self.n_views) if self.owned[v]}
         gathered: List[Optional[dict]] = [None] * self.world
         self.dist.all_gather_object(gathered, mine, group=self.group)

@@ -225,6 +225,183 @@ class OracleBlockEngine(OracleEngine):
             raise ValueError(f"phase {ph} is not part of the replicated-chains layout")
 
 
+class OracleSliceEngine(OracleBlockEngine):
+    """Stand-in for the ROW-SLICED chains layout (slice_chains): rank r keeps rows (columns) slice r of EVERY view's F (G)
+    current and walks the F (G) chain of all views on it; the exchange buffers are CPU tensors holding what the library's
+    hold, in exact fp64 -- U / T slices (T chunks followed by the own view's S and F'^T F': what the G rule needs besides
+    the rows), new F / G rows on their way back to the owners, S blocks [S old | F'^T X G' | F'^T F' | G'^T G' | colSums(G')
+    | colSums(F') | ||X||^2].  Rules and association order as OracleBlockEngine (R/update_steps.r:141-251 on the products)."""
+    supports_sliced = True
+
+    def __init__(self, prob, owned, rank, world):
+        super().__init__(prob, owned)
+        t, k = self.torch, self.k
+        self.rank, self.world = rank, world
+        n, m = self.nm[0]
+        up = lambda a, b: (a + b - 1) // b * b
+        self.per_r, self.per_c = up((n + world - 1) // world, 8), up((m + world - 1) // world, 8)
+        z = lambda count: t.zeros(count, dtype=t.float64)
+        self.buf = {"U_SEND": z(world * self.per_r * k), "U_RECV": z(world * self.per_r * k),
+                    "FNEW_SEND": z(world * self.per_r * k), "FNEW_RECV": z(world * self.per_r * k),
+                    "T_SEND": z(world * (self.per_c * k + 2 * k * k)), "T_RECV": z(world * (self.per_c * k + 2 * k * k)),
+                    "GNEW_SEND": z(world * self.per_c * k), "GNEW_RECV": z(world * self.per_c * k)}
+        self.sblk = [z(4 * k * k + 2 * k + 1) for _ in self.nm]
+        self.tol, self.done, self.stop_sweep, self.prev_mean, self.closed = -1.0, False, 0, 0.0, 0
+
+    def slice_info(self):
+        return self.per_r, self.per_c
+
+    def set_stop_tolerance(self, tol):
+        self.tol = tol
+
+    def loop_state(self):
+        return self.closed, self.done, self.stop_sweep
+
+    def _rows(self, per, full):
+        lo = min(self.rank * per, full)
+        return lo, min(lo + per, full)
+
+    def _pack(self, key, mat, per, tail=None):
+        k, chunk = self.k, per * self.k + (0 if tail is None else tail.size)
+        buf = self.buf[key].numpy()
+        for c in range(self.world):
+            rows = mat[c * per:(c + 1) * per]
+            buf[c * chunk:c * chunk + rows.size] = rows.ravel()
+            if tail is not None:
+                buf[c * chunk + per * k:(c + 1) * chunk] = tail
+
+    def prepare(self):
+        super().prepare()
+        v = self.rank
+        n = self.nm[v][0]
+        self._pack("U_SEND", self.fblk[v].numpy()[:n * self.k].reshape(n, self.k), self.per_r)
+
+    def factor_tensor(self, v, which):
+        if which in self.buf:
+            return self.buf[which]
+        return super().factor_tensor(v, which)
+
+    def _chain(self, is_g):
+        """update_f / update_g of every view, in view order, on my slice (R/update_steps.r:141-165 / :180-207)."""
+        p, k, V = self.prob, self.k, self.n_v
+        full = self.nm[0][1] if is_g else self.nm[0][0]
+        per = self.per_c if is_g else self.per_r
+        lo, hi = self._rows(per, full)
+        recv = self.buf["T_RECV" if is_g else "U_RECV"].numpy()
+        chunk = per * k + (2 * k * k if is_g else 0)
+        out = self.buf["GNEW_SEND" if is_g else "FNEW_SEND"].numpy()
+        state = self.G if is_g else self.F
+        rest = p.psi if is_g else p.phi
+        run = [state[c].numpy()[lo:hi].copy() for c in range(V)]                 # running values of the slice
+        for w in range(V):
+            prod = recv[w * chunk:w * chunk + (hi - lo) * k].reshape(hi - lo, k)
+            if is_g:
+                tail = recv[w * chunk + per * k:(w + 1) * chunk]
+                sm, gram = tail[:k * k].reshape(k, k), tail[k * k:].reshape(k, k)
+                lm = self.mu_all[w].numpy()
+                numerator = prod @ sm                                              # :185
+                denominator = (run[w] @ sm.T) @ (gram @ sm)                        # :186-187
+                unrestricted = rest.sum() == 0                                     # :190 (whole matrix)
+            else:
+                nrow = self.nm[w][0]
+                blk = self.fblk[w].numpy()
+                sm, gram = blk[nrow * k:nrow * k + k * k].reshape(k, k), blk[nrow * k + k * k:nrow * k + 2 * k * k].reshape(k, k)
+                lm = blk[nrow * k + 2 * k * k:]
+                numerator = prod @ sm.T                                            # :146
+                denominator = (run[w] @ sm) @ (gram @ sm.T)                        # :147-148
+                unrestricted = rest[:, w].sum() == 0                               # :152
+            lm_mat = 0.5 * np.tile(lm, (hi - lo, 1))                               # :151 / :188
+            if unrestricted:
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    ratio = numerator / (denominator + lm_mat)
+                ratio[np.isnan(ratio)] = 1.0
+                new = run[w] * ratio
+            else:
+                vec = rest[:, w]
+                acc = 0.0                                                          # star_prod_relevant with every row shared in
+                for i in range(V):                                                 # the same order (R/utils.r:63-78)
+                    if vec[i] != 0:
+                        acc = acc + vec[i] * run[i] * full                         # :73  (masked = the coupled view's rows)
+                num_prod = acc / full                                              # :77
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    new = run[w] * ((numerator + num_prod) / (denominator + vec.sum() * run[w] + lm_mat))
+            run[w] = np.abs(new)
+            state[w].numpy()[lo:hi] = run[w]
+            out[w * per * k:w * per * k + (hi - lo) * k] = run[w].ravel()
+
+    def phase(self, v, ph, sweep):
+        from resnmtf_amd._lib import PHASE_S_ALL, PHASE_SLICE_F, PHASE_SLICE_G, PHASE_SLICE_XG, PHASE_SLICE_XTF
+        if self.tol >= 0 and self.done:
+            return
+        O, p, k = self.O, self.prob, self.k
+        n, m = self.nm[v]
+        if ph == PHASE_SLICE_F:
+            self._chain(False)
+        elif ph == PHASE_SLICE_G:
+            self._chain(True)
+        elif ph == PHASE_SLICE_XTF:                                          # received rows -> whole F' of the own view; T, F'^T F'
+            f = self.buf["FNEW_RECV"].numpy()[:n * k].reshape(n, k)
+            self.F[v].copy_(self.torch.from_numpy(f.copy()))
+            tail = np.concatenate([self.S[v].numpy().ravel(), (f.T @ f).ravel()])
+            tt = p.data[v].T @ f
+            self._tt = tt
+            self._pack("T_SEND", tt, self.per_c, tail)
+        elif ph == PHASE_SLICE_XG:
+            g = self.buf["GNEW_RECV"].numpy()[:m * k].reshape(m, k)
+            self.G[v].copy_(self.torch.from_numpy(g.copy()))
+            f = self.F[v].numpy()
+            blk = self.sblk[v].numpy()
+            blk[:k * k] = self.S[v].numpy().ravel()
+            blk[k * k:2 * k * k] = ((f.T @ p.data[v]) @ g).ravel()           # :223
+            blk[2 * k * k:3 * k * k] = (f.T @ f).ravel()
+            blk[3 * k * k:4 * k * k] = (g.T @ g).ravel()
+            blk[4 * k * k:4 * k * k + k] = g.sum(0)
+            blk[4 * k * k + k:4 * k * k + 2 * k] = f.sum(0)
+            blk[4 * k * k + 2 * k] = self.norms[v]
+            self._pack("U_SEND", p.data[v] @ g, self.per_r)
+        elif ph == PHASE_S_ALL:                                              # update_s chain, update_lm, error of every view
+            kk = k * k
+            run = [self.sblk[w].numpy()[:kk].reshape(k, k).copy() for w in range(self.n_v)]
+            errs = []
+            for w in range(self.n_v):
+                blk = self.sblk[w].numpy()
+                nn, ftf, gtg = blk[kk:2 * kk].reshape(k, k), blk[2 * kk:3 * kk].reshape(k, k), blk[3 * kk:4 * kk].reshape(k, k)
+                cur = run[w]
+                denominator = (ftf @ cur) @ gtg                              # :224
+                if p.xi.sum() == 0:                                          # :226
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        ratio = nn / denominator
+                    ratio[np.isnan(ratio)] = 1.0
+                    new = cur * ratio
+                else:
+                    xi_vec = p.xi[:, w]
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        new = cur * ((nn + O.star_prod(xi_vec, run)) / (denominator + xi_vec.sum() * cur))
+                run[w] = np.abs(new)
+                self.S[w].copy_(self.torch.from_numpy(run[w]))
+                self.lam_all[w] = self.lam_all[w] * self.torch.from_numpy(blk[4 * kk + k:4 * kk + 2 * k].copy())   # :249-251, :312-313
+                self.mu_all[w] = self.mu_all[w] * self.torch.from_numpy(blk[4 * kk:4 * kk + k].copy())
+                nrow = self.nm[w][0]
+                fb = self.fblk[w].numpy()
+                fb[nrow * k:nrow * k + kk] = run[w].ravel()
+                fb[nrow * k + kk:nrow * k + 2 * kk] = gtg.ravel()
+                fb[nrow * k + 2 * kk:] = self.lam_all[w].numpy()
+                xn = blk[4 * kk + 2 * k]                                     # trace form (the library's, R/utils.r:157-166)
+                errs.append((xn - 2.0 * np.sum(run[w] * nn) + np.sum(((ftf @ run[w]) @ gtg) * run[w])) / xn)
+                if self.owned[w]:
+                    x = p.data[w]
+                    x_hat = (self.F[w].numpy() @ run[w]) @ self.G[w].numpy().T
+                    self.errs[w].append(np.linalg.norm(x - x_hat, "fro") ** 2 / self.norms[w])
+            self.closed += 1
+            if self.tol >= 0:                                                # R/main.r:55,77-80
+                mean = float(np.sum(errs) / self.n_v)
+                if not (abs(mean - self.prev_mean) > self.tol):
+                    self.done, self.stop_sweep = True, self.closed
+                self.prev_mean = mean
+        else:
+            raise ValueError(f"phase {ph} is not part of the sliced-chains layout")
+
+
 def build_problem():
     """3 views, phi + psi + xi coupled, rows/columns partially shared at different positions."""
     from resnmtf_amd.synth import Problem, planted_view, random_init
@@ -276,12 +453,24 @@ def build_problem_gs(world, k=5):
     return prob
 
 
+def build_problem_slice(world, k=5, n=96, m=72):
+    """One view per rank, equal shapes, phi + psi + xi coupling, every row / column shared in the same order (the
+    reference's auto-naming, R/utils.r:482-491): the layout the row-sliced chains need."""
+    from resnmtf_amd import sharded
+    prob = sharded.local_problem(world, (n, m), k, phi=1.5, xi=0.4, psi=1.0)
+    return prob
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rank", type=int, required=True)
     ap.add_argument("--world", type=int, required=True)
     ap.add_argument("--port", type=int, required=True)
-    ap.add_argument("--mode", choices=["cpu", "cpu_gs", "gpu", "gpu_gs", "gpu_norep", "gpu_allgather", "gpu_chain", "gpu_chain_off", "gpu_graph1", "gpu_gs_rccl1"], required=True)
+    ap.add_argument("--mode", choices=["cpu", "cpu_gs", "gpu", "gpu_gs", "gpu_norep", "gpu_allgather", "gpu_chain", "gpu_chain_off", "gpu_graph1", "gpu_gs_rccl1",
+                                       "cpu_slice", "cpu_slice_conv", "gpu_slice", "gpu_slice_conv", "gpu_gs_conv", "gpu_slice_rccl1", "gpu_gs_graph1"], required=True)
+    ap.add_argument("--n", type=int, default=96)
+    ap.add_argument("--m", type=int, default=72)
+    ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--sweeps", type=int, default=12)
     ap.add_argument("--xi", type=float, default=0.4)
     ap.add_argument("--k", type=int, default=5)
@@ -311,6 +500,25 @@ def main():
         np.savez(a.out, same=np.array(same), all_error=outs[1][0])
         dist.destroy_process_group()
         return
+    if a.mode == "gpu_gs_graph1":       # one rank on RCCL, replicated G / S chains: captured chunks against the eager loop
+        import torch
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        prob = sharded.local_problem(1, (512, 192), a.k, owned=[0])
+        outs = []
+        for chunk in (0, 4):
+            drv = sharded.ShardedSweep(prob, [0], 0, 1, device_index=0, replicate_f="force", replicate_gs=True)
+            assert drv.replicate_gs and not drv.sliced
+            drv.run(5, graph_chunk=chunk)
+            drv.run(a.sweeps - 5, graph_chunk=chunk)
+            torch.cuda.synchronize()
+            outs.append((drv.mean_errors(), drv.gather_results(0)))
+            drv.close()
+        same = np.array_equal(outs[0][0], outs[1][0]) and all(
+            np.array_equal(x, y) for key in outs[0][1] for x, y in zip(outs[0][1][key], outs[1][1][key]))
+        np.savez(a.out, same=np.array(same), all_error=outs[1][0])
+        dist.destroy_process_group()
+        return
     if a.mode == "gpu_gs_rccl1":        # one rank on RCCL: the replicated-chains layout with the in-place all-gathers over the arenas
         import torch
         from helpers import rel_fro, run_oracle
@@ -329,7 +537,28 @@ def main():
         np.savez(a.out, same=np.array(ok), all_error=errs)
         dist.destroy_process_group()
         return
+    if a.mode == "gpu_slice_rccl1":     # one rank on RCCL: the sliced layout's all-to-alls, second communicator and stream
+        import torch
+        from helpers import rel_fro, run_oracle
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        prob = sharded.local_problem(1, (a.n, a.m), a.k, owned=[0])
+        drv = sharded.ShardedSweep(prob, [0], 0, 1, device_index=0, replicate_f="force", replicate_gs=True, slice_chains=True)
+        assert drv.sliced and drv._group_u is not None
+        drv.run(a.sweeps // 2); drv.run(a.sweeps - a.sweeps // 2)
+        torch.cuda.synchronize()
+        errs = drv.mean_errors(); res = drv.gather_results(0)
+        drv.close()
+        ref = run_oracle(prob, n_iters=a.sweeps)
+        ok = (np.allclose(errs, ref["All_Error"], atol=2e-5) and rel_fro(res["output_f"][0], ref["output_f"][0]) < 2e-5 and
+              rel_fro(res["output_g"][0], ref["output_g"][0]) < 2e-5 and rel_fro(res["output_s"][0], ref["output_s"][0]) < 1e-4)
+        np.savez(a.out, same=np.array(ok), all_error=errs)
+        dist.destroy_process_group()
+        return
     dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
+    if a.mode in ("cpu_slice", "cpu_slice_conv", "gpu_slice", "gpu_slice_conv", "gpu_gs_conv"):
+        slice_main(a, dist, sharded)
+        return
     one_per_rank = a.mode in ("gpu_allgather", "gpu_chain", "gpu_chain_off")
     gs = a.mode in ("cpu_gs", "gpu_gs")
     prob = (build_problem_gs(a.world, a.k) if gs else
@@ -366,6 +595,64 @@ def main():
     drv.close()
     if a.rank == 0:
         out = {"all_error": errs, "mirrors_ok": np.array(mirrors_ok)}
+        for key, lst in res.items():
+            for v, arr in enumerate(lst):
+                out[f"{key}{v}"] = arr
+        np.savez(a.out, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def slice_main(a, dist, sharded):
+    """Row-sliced chains (and the convergence mode of the replicated-chains layouts): stand-in engine on CPU or the HIP
+    engine with the ranks sharing one GPU."""
+    prob = build_problem_slice(a.world, a.k, a.n, a.m)
+    n_v = a.world
+    owner_of = list(range(n_v))
+    conv = a.mode.endswith("_conv")
+    extra = {}
+
+    def make(sliced, **opts):
+        if a.mode.startswith("cpu"):
+            return sharded.ShardedSweep(prob, owner_of, a.rank, a.world, replicate_f=True, slice_chains=True,
+                                        engine_factory=lambda p, owned: OracleSliceEngine(p, owned, a.rank, a.world))
+        return sharded.ShardedSweep(prob, owner_of, a.rank, a.world, device_index=0, slice_chains=sliced, **opts)
+
+    def results(drv):
+        errs = drv.mean_errors()
+        res = drv.gather_results(0)
+        raw = None
+        if not a.mode.startswith("cpu"):
+            import torch
+            drv.engine.synchronize(); torch.cuda.synchronize()
+            raw = b"".join(drv.engine.factor_tensor(a.rank, kd).cpu().numpy().tobytes() for kd in ("F", "G", "S"))
+        return errs, res, raw
+
+    drv = make(a.mode != "gpu_gs_conv", kk_mode=2)
+    assert drv.sliced == (a.mode != "gpu_gs_conv") and drv.replicate_gs
+    if conv:
+        done = drv.run(None, tol=a.tol, max_iters=a.sweeps, check_every=7)
+        extra["sweeps_done"] = np.array(done)
+        alld = [None] * a.world
+        dist.all_gather_object(alld, int(done))
+        extra["same_stop"] = np.array(len(set(alld)) == 1)
+    else:
+        drv.run(a.sweeps // 2)
+        drv.run(a.sweeps - a.sweeps // 2)          # two calls: state carries over
+    errs, res, raw = results(drv)
+    drv.close()
+    if a.mode == "gpu_slice":                      # the same run with the chains REPLICATED (same hand-off mode): bitwise
+        drv2 = make(False, kk_mode=2)
+        assert not drv2.sliced and drv2.replicate_gs
+        drv2.run(a.sweeps // 2)
+        drv2.run(a.sweeps - a.sweeps // 2)
+        errs2, res2, raw2 = results(drv2)
+        drv2.close()
+        same = [None] * a.world
+        dist.all_gather_object(same, bool(raw == raw2 and np.array_equal(errs, errs2)))
+        extra["bitwise_vs_replicated"] = np.array(all(same))
+    if a.rank == 0:
+        out = {"all_error": errs, **extra}
         for key, lst in res.items():
             for v, arr in enumerate(lst):
                 out[f"{key}{v}"] = arr

@@ -10,6 +10,7 @@ import pytest
 
 from helpers import ROOT, golden_problem, load_golden, rel_fro, run_oracle
 from resnmtf_amd import naming
+from test_gpu_parity import check_clusters
 
 
 def build_driver(tmp_path):
@@ -84,4 +85,5 @@ def test_c_driver_matches_golden(tmp_path, name):
         assert rel_fro(res["f"][v], g["out_f"][v]) < 2e-5
         assert rel_fro(res["g"][v], g["out_g"][v]) < 2e-5
         assert rel_fro(res["s"][v], g["out_s"][v]) < 1e-4
-        assert (res["rc"][v] != g["rc"][v]).sum() <= 1 and (res["cc"][v] != g["cc"][v]).sum() <= 1
+        # binary cluster matrices through the C-ABI caller: identical, a difference allowed only on the 1/n threshold
+        check_clusters(res["rc"][v], res["cc"][v], g["out_f"][v], g["out_s"][v], g["out_g"][v], g["rc"][v], g["cc"][v], res["s"][v], view=v)

@@ -373,17 +373,20 @@ def test_device_svd_init_matches_oracle(shape, k):
 def test_bf16_split_option_stays_inside_the_bar(shapes, k, kw):
     """resnmtf_options.bf16_split for k > 16.  0 (default): three bf16 pieces per operand (exact truncation split), six
     products on the K = 32 bf16 MFMA in wide workgroups, f32-grade -- held to the same 2e-5 as everything else.  2: the
-    plain f32 MFMA, one tile per workgroup -- same tolerance.  (1, the former two-piece form, is an alias of 0.)"""
+    plain f32 MFMA, one tile per workgroup -- same tolerance.  (1, the former two-piece form, is retired and REFUSED: a
+    caller that asked for its speed / precision trade must not silently get another one.)"""
+    from resnmtf_amd._lib import ResnmtfError
     prob = synth.make_problem(shapes, k, **kw)
     ref = run_oracle(prob, n_iters=30)
     outs = {}
-    for mode in (0, 2, 1):
+    for mode in (0, 2):
         res = run_hip(prob, n_iters=30, bf16_split=mode)
         check_against(res, ref["output_f"], ref["output_s"], ref["output_g"], ref["row_clusters"], ref["col_clusters"],
                       ref["All_Error"])
         outs[mode] = res["output_f"][0]
     assert not np.array_equal(outs[0], outs[2])        # two distinct arithmetic forms
-    assert np.array_equal(outs[0], outs[1])
+    with pytest.raises(ResnmtfError, match="retired"):
+        run_hip(prob, n_iters=2, bf16_split=1)
 
 
 @pytest.mark.parametrize("shape,k", [((5, 4), 2), ((17, 3), 3), ((63, 65), 2), ((64, 64), 16), ((3, 70), 2), ((200, 2), 2)])

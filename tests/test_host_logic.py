@@ -86,7 +86,7 @@ def test_library_loads_and_exports_header_symbols():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.resnmtf_abi_version() == 1
+    assert lib.resnmtf_abi_version() == _lib.ABI_VERSION == 2
     assert lib.resnmtf_device_count() >= 0
 
 
