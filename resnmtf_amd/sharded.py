@@ -659,7 +659,9 @@ class ShardedSweep:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             before = self.sweeps_done
-            with torch.cuda.graph(g, stream=self._tstream):
+            # thread-local capture mode: the process group's watchdog thread polls the events of earlier (eager) collectives
+            # while this thread captures -- in the default (global) mode such a call from ANY thread invalidates the capture
+            with torch.cuda.graph(g, stream=self._tstream, capture_error_mode="thread_local"):
                 self._run(chunk)
             self.sweeps_done = before                   # capturing enqueued nothing
             graphs[chunk] = g
