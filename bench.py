@@ -117,6 +117,8 @@ def run_single(args) -> dict:
     def make_engine(**kw):
         if os.environ.get("RESNMTF_NO_GRAPH") == "1":      # profiling runs: plain launches, one row per dispatch
             kw.setdefault("use_graph", False)
+        if os.environ.get("RESNMTF_FUSE_UPDATES"):         # A/B (opt-in, measured slower): 1 = updates fused into the consuming pass launch, 2 = without prefetch
+            kw.setdefault("fuse_updates", int(os.environ["RESNMTF_FUSE_UPDATES"]))
         e = Engine([n], [m], [k], device_id=0, **kw)
         t0 = time.perf_counter()
         e.set_view(0, prob.data[0])

@@ -175,6 +175,14 @@ typedef struct resnmtf_options {
                              hand-off mode B is used at every k.  Otherwise fall back to replicate_gs. */
   int slice_index;        /* which slice this handle walks (= the rank) */
   int slice_count;        /* number of slices (= ranks = views) */
+  int fuse_updates;       /* 0 (default): every factor update is a launch of its own.  1 / 2 (opt-in, k <= 16, hand-off mode A, f32
+                             images): an UNCOUPLED update_f / update_g (R/update_steps.r:152-155 / :190-193) runs in the first
+                             workgroups of the Xt.F / X.G' launch that consumes it, the other workgroups wait for it on an arrival
+                             flag (1: with the first trip of X rows requested before the wait, 2: without).  Bitwise the same
+                             results (tested), one launch per update less -- but MEASURED SLOWER on MI355X (c2: 52 - 62 us per
+                             sweep against 43): publishing a row block to the other XCDs takes an agent-scope release (an L2
+                             write-back), 0.3 - 0.5 us per workgroup and serial within an XCD, so the flag rises 4 - 7 us after the
+                             last block is done (profiles/r03_stamps_fused_c2_*.txt) */
 } resnmtf_options;
 
 typedef struct resnmtf_pass_timing {

@@ -67,6 +67,7 @@ struct ViewState {
   int tw_xg = 8, tw_xtf = 8;         // k > 16 (wide form): 64-column tiles per workgroup
   float *Pxg = nullptr, *Pxtf = nullptr, *Paux_xg = nullptr, *Paux_xtf = nullptr;
   int *cnt_xg = nullptr, *cnt_xtf = nullptr;
+  int* fuse_cnt = nullptr;           // [2] arrivals of the update blocks fused into the Xt.F ([0]) / X.G ([1]) launch (pass_fused_kernel)
   int rpbF = 16, nblkF = 1, rpbG = 16, nblkG = 1;
   void* fblk = nullptr;              // replicate_f: [Usum | Ma_F | Md_F | lambda] contiguous (the F-update's inputs), a
   size_t fblk_bytes = 0;             // slice of the handle's arena; Usum = the X.G split slabs folded into one f32 slab
@@ -133,6 +134,8 @@ struct resnmtf_handle {
   double* sblk_base = nullptr; size_t sblk_step = 0;           // S block of view v = sblk_base + v * sblk_step (doubles)
   int* view_sweep = nullptr;          // replicate_gs: [V] sweeps closed per view (s_chain_kernel) + [1] its arrival counter
   double phase_tol = -1.0;            // phase API: >= 0 = convergence mode (resnmtf_set_stop_tolerance)
+  int* fuse_err = nullptr;            // pinned, device-mapped: set by a fused pass launch whose wait for its update blocks ran out
+  int* fuse_err_dev = nullptr;
   // slice_chains: rank r walks the F (G) chain of every view on the row (column) slice r; exchange buffers of the four
   // all-to-alls of a sweep (V chunks each) and the two chain launches
   bool sliced = false;
@@ -195,7 +198,7 @@ void free_view(ViewState& v) {
   if (v.fblk) { v.fblk = nullptr; v.Usum = nullptr; v.Ma_F = nullptr; v.Md_F = nullptr; v.lambda = nullptr; }   // arena slices
   if (v.gblk) { v.gblk = nullptr; v.Tsum = nullptr; v.Ma_G = nullptr; v.Md_G = nullptr; v.mu = nullptr; }
   v.sblk = nullptr;
-  void* ptrs[] = {v.Fk, v.Gk, v.X16, v.Xt16, v.X32, v.Xt32, v.xnorm2, v.F, v.G, v.S, v.lambda, v.mu, v.F32, v.G32, v.T32, v.Pxg, v.Pxtf,
+  void* ptrs[] = {v.fuse_cnt, v.Fk, v.Gk, v.X16, v.Xt16, v.X32, v.Xt32, v.xnorm2, v.F, v.G, v.S, v.lambda, v.mu, v.F32, v.G32, v.T32, v.Pxg, v.Pxtf,
                   v.Paux_xg, v.Paux_xtf, v.cnt_xg, v.cnt_xtf, v.partF, v.partG, v.FtF, v.FtFS, v.cF, v.Ma_F, v.Md_F, v.Ma_G, v.Md_G};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -286,6 +289,11 @@ hipError_t set_all_attrs() {
   TRY_ATTR(set_smem_attrs<48>()); TRY_ATTR(set_smem_attrs<64>());
   TRY_ATTR((set_pass_attr<1, 4, 8>())); TRY_ATTR((set_pass_attr<1, 8, 8>())); TRY_ATTR((set_pass_attr<1, 8, 4>())); TRY_ATTR((set_pass_attr<1, 16, 8>()));
   TRY_ATTR((set_pass_attr<2, 8, 4>())); TRY_ATTR((set_pass_attr<3, 8, 4>())); TRY_ATTR((set_pass_attr<4, 8, 4>()));
+  for (const void* fn : {reinterpret_cast<const void*>(&pass_fused_kernel<8, false, true>), reinterpret_cast<const void*>(&pass_fused_kernel<8, true, true>),
+                         reinterpret_cast<const void*>(&pass_fused_kernel<4, false, true>), reinterpret_cast<const void*>(&pass_fused_kernel<4, true, true>),
+                         reinterpret_cast<const void*>(&pass_fused_kernel<8, false, false>), reinterpret_cast<const void*>(&pass_fused_kernel<8, true, false>),
+                         reinterpret_cast<const void*>(&pass_fused_kernel<4, false, false>), reinterpret_cast<const void*>(&pass_fused_kernel<4, true, false>)})
+    TRY_ATTR(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
 #define S_CHAIN_ATTR(KPV, NVBV) TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&s_chain_kernel<KPV, NVBV>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds))
   S_CHAIN_ATTR(16, 4); S_CHAIN_ATTR(16, 8); S_CHAIN_ATTR(16, RESNMTF_MAX_COUPLE + 1);
   S_CHAIN_ATTR(32, 4); S_CHAIN_ATTR(32, 8); S_CHAIN_ATTR(32, RESNMTF_MAX_COUPLE + 1);
@@ -320,7 +328,17 @@ int max_pass_waves(int NT) { return NT <= 1 ? 16 : 8; }
 int pass_blocks_per_cu(int NT, int nw) { return pass_min_blocks(NT, nw); }
 
 // xg = false: Xt.F pass + kk_f;  xg = true: X.G pass + kk_s (mode 0 = run prologue, 1 = full S update)
-void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, double tol, bool check_done) {
+// can the F (kind 0) / G (kind 1) update of view v ride in the pass launch that consumes it (pass_fused_kernel)?  Mode A at
+// k <= 16 with the f32 images and 8-wave workgroups, the unrestricted update form (the coupled forms exceed the pass's
+// register budget), and few enough row blocks that every updater is resident among the launch's first workgroups
+bool can_fuse_update(const resnmtf_handle* h, const ViewState& v, int kind) {
+  if (h->opt.fuse_updates == 0 || v.kk_mode != 0 || v.NT != 1 || v.half || !v.fuse_cnt) return false;
+  const UpdateArgs& u = kind == 0 ? v.argF : v.argG;
+  const PassArgs& p = kind == 0 ? v.passXtF : v.passXG;
+  const int nblk = kind == 0 ? v.nblkF : v.nblkG, nw = kind == 0 ? v.nw_xtf : v.nw_xg;
+  return nw == 8 && !u.restricted && nblk <= p.ntiles * p.nsplit && nblk <= h->n_cu;
+}
+void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, double tol, bool check_done, bool fuse_update = false) {
   PassArgs a = xg ? v.passXG : v.passXtF;
   a.check_done = check_done ? 1 : 0;
   KKFArgs kf = v.argKF;
@@ -328,6 +346,7 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
   ks.mode = mode; ks.tol = tol;
   // mode A: the k x k job is workgroup 0 and reads the update kernel's fp64 partials
   a.kk_block0 = (v.kk_mode == 0) ? 1 : 0;
+  a.fuse_zero = (a.kk_block0 && v.fuse_cnt && !v.half) ? v.fuse_cnt + (xg ? 0 : 2) : nullptr;   // the sibling launch's arrival counter
   if (!a.kk_block0) { kf.part = nullptr; ks.part = nullptr; }
   const int nw = xg ? v.nw_xg : v.nw_xtf;
   // MFMA form of the main tiles (resnmtf_options.bf16_split): k <= 16 always the f32 MFMA; k > 16: three bf16 pieces per
@@ -340,6 +359,26 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
   // the elapsed time is the kernel's own begin->end, the same quantity rocprofv3 --kernel-trace reports
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   const bool timed = take_events(h, xg ? RESNMTF_TIMED_XG : RESNMTF_TIMED_XTF, &ev0, &ev1);
+  if (fuse_update) {   // the update that feeds this pass rides in its first workgroups (pass_fused_kernel)
+    UpdateArgs u = xg ? v.argG : v.argF;
+    u.check_done = 0; u.gram_only = 0;
+    FuseArgs fz{};
+    fz.cnt_own = v.fuse_cnt + (xg ? 2 : 0);      // [0] arrivals, [1] the flag the waiters poll
+    { static const int nap = std::getenv("RESNMTF_FUSE_NAP") ? std::atoi(std::getenv("RESNMTF_FUSE_NAP")) : 2; fz.nap = nap; }
+    fz.n_upd = xg ? v.nblkG : v.nblkF; fz.err = h->fuse_err_dev;
+    const size_t smem_f = std::min<size_t>(std::max(smem, update_smem_bytes(16)), kMaxLds);
+    const bool pp = xg ? v.pp_xg : v.pp_xtf;
+    const bool pre = h->opt.fuse_updates == 1;   // (2: without the prefetch of the first X trip)
+#define LAUNCH_FUSED_P(UV, XG, PV)                                                                                              \
+    if (timed) hipExtLaunchKernelGGL((pass_fused_kernel<UV, XG, PV>), grid, block, smem_f, h->stream, ev0, ev1, 0, a, kf, ks, u, fz);    \
+    else hipLaunchKernelGGL((pass_fused_kernel<UV, XG, PV>), grid, block, smem_f, h->stream, a, kf, ks, u, fz)
+#define LAUNCH_FUSED(UV, XG) if (pre) { LAUNCH_FUSED_P(UV, XG, true); } else { LAUNCH_FUSED_P(UV, XG, false); }
+    if (xg) { if (pp) { LAUNCH_FUSED(4, true); } else { LAUNCH_FUSED(8, true); } }
+    else { if (pp) { LAUNCH_FUSED(4, false); } else { LAUNCH_FUSED(8, false); } }
+#undef LAUNCH_FUSED
+#undef LAUNCH_FUSED_P
+    return;
+  }
   if (v.half) {       // fp16 image of X: the run-time scale (set at upload) is taken out in the slab store
     a.out_scale = v.u16 ? 1.f / v.xscale : 1.f / (v.xscale * RESNMTF_B16_SCALE);
     // wave-steps per trip: 4 for fp16; 2 for the 16-bit integers (their widening to f32 wants the registers: c2 26.5 k
@@ -600,10 +639,12 @@ int launch_s_chain(resnmtf_handle* h, bool checked) {
 #undef S_CHAIN
   return RESNMTF_OK;
 }
-void enqueue_phase_g(resnmtf_handle* h, const ViewState& v, double tol, bool checked) {
-  launch_pass(h, v, false, 1, tol, checked);
-  launch_update(h, v, 1, checked);
-  launch_pass(h, v, true, 1, tol, checked);
+// fuse_f: the view's F update has NOT been enqueued -- it rides in the Xt.F launch (enqueue_sweep decides)
+void enqueue_phase_g(resnmtf_handle* h, const ViewState& v, double tol, bool checked, bool fuse_f = false) {
+  launch_pass(h, v, false, 1, tol, checked, fuse_f);
+  const bool fuse_g = can_fuse_update(h, v, 1);
+  if (!fuse_g) launch_update(h, v, 1, checked);
+  launch_pass(h, v, true, 1, tol, checked, fuse_g);
   launch_fold(h, v);
 }
 // run prologue of one view: X.G launch whose kk_s runs in mode 0 (F coefficients from the current S, G);
@@ -623,8 +664,9 @@ void enqueue_sweep(resnmtf_handle* h, double tol) {
   if (hoist) enqueue_phase_f_all(h, checked);
   for (const auto& v : h->views) {
     if (!v.owned) continue;
-    if (!hoist) enqueue_phase_f(h, v, checked);
-    enqueue_phase_g(h, v, tol, checked);
+    const bool fuse_f = !hoist && can_fuse_update(h, v, 0);
+    if (!hoist && !fuse_f) enqueue_phase_f(h, v, checked);
+    enqueue_phase_g(h, v, tol, checked, fuse_f);
   }
 }
 
@@ -851,6 +893,11 @@ hipError_t alloc_host_mirrors(resnmtf_handle* h, int cap) {
   if (e != hipSuccess) return e;
   std::memset(h->err_host, 0, (size_t)cap * h->V * sizeof(double));
   if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->err_host_dev), h->err_host, 0)) != hipSuccess) return e;
+  if (!h->fuse_err) {
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->fuse_err), sizeof(int), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return e;
+    *h->fuse_err = 0;
+    if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->fuse_err_dev), h->fuse_err, 0)) != hipSuccess) return e;
+  }
   if (!h->ctl_host) {
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->ctl_host), sizeof(SweepCtl), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return e;
     std::memset(h->ctl_host, 0, sizeof(SweepCtl));
@@ -1171,6 +1218,7 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
       if ((e = dev_alloc_zero(&vs.Fk, (size_t)vs.n_pad * vs.KP * 3)) != hipSuccess) return bail(e, "hipMalloc Fk");
       if ((e = dev_alloc_zero(&vs.Gk, (size_t)vs.m_pad * vs.KP * 3)) != hipSuccess) return bail(e, "hipMalloc Gk");
     }
+    if ((e = dev_alloc_zero(&vs.fuse_cnt, 4)) != hipSuccess) return bail(e, "hipMalloc cnt");
     if ((e = dev_alloc_zero(&vs.cnt_xg, 4)) != hipSuccess) return bail(e, "hipMalloc cnt");
     if ((e = dev_alloc_zero(&vs.cnt_xtf, 4)) != hipSuccess) return bail(e, "hipMalloc cnt");
     for (double** pp : {&vs.FtF, &vs.FtFS})
@@ -1217,6 +1265,7 @@ int resnmtf_destroy(resnmtf_handle* h) {
   if (h->err) (void)hipFree(h->err);
   if (h->err_host) (void)hipHostFree(h->err_host);
   if (h->ctl_host) (void)hipHostFree(h->ctl_host);
+  if (h->fuse_err) (void)hipHostFree(h->fuse_err);
   for (auto& evt : h->ev)
     if (evt) (void)hipEventDestroy(evt);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -2114,6 +2163,8 @@ static int prepare_impl(resnmtf_handle* h, bool allow_resume, bool keep_ctl = fa
   // run prologue: F coefficients and the first X.G pass of every owned view
   h->resume_ok = false;
   for (const auto& v : h->views)
+    if (v.owned && v.fuse_cnt) HIP_TRY(h, hipMemsetAsync(v.fuse_cnt, 0, 4 * sizeof(int), h->stream));
+  for (const auto& v : h->views)
     if (v.owned) enqueue_prologue(h, v);
   HIP_TRY(h, hipGetLastError());
   return RESNMTF_OK;
@@ -2301,6 +2352,11 @@ int resnmtf_run(resnmtf_handle* h, int n_iters, double tol, int max_iters, doubl
       if (int rc = sync_both(h)) return rc;
   } else if (int rc = sync_both(h)) return rc;
   if (trace) tp[3] = clk::now();
+  if (h->fuse_err && *h->fuse_err) {
+    *h->fuse_err = 0;
+    h->resume_ok = false;
+    return h->fail(RESNMTF_ERR_HIP, "a fused pass launch gave up waiting for its update blocks (pass_fused_kernel): results are invalid");
+  }
   const int done_total = h->ctl_host->sweep - base;
   if (tol_arg < 0.0 && done_total != total) return h->fail(RESNMTF_ERR_HIP, "sweep counter mismatch");
   if (all_err && done_total > 0) {
@@ -2488,7 +2544,12 @@ int resnmtf_view_errors(resnmtf_handle* h, int v, int first, int count, double* 
 int resnmtf_synchronize(resnmtf_handle* h) {
   if (!h) return RESNMTF_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
-  return sync_both(h);
+  if (int rc = sync_both(h)) return rc;
+  if (h->fuse_err && *h->fuse_err) {
+    *h->fuse_err = 0;
+    return h->fail(RESNMTF_ERR_HIP, "a fused pass launch gave up waiting for its update blocks (pass_fused_kernel): results are invalid");
+  }
+  return RESNMTF_OK;
 }
 
 #ifdef RESNMTF_STAMPS
@@ -2520,8 +2581,10 @@ int resnmtf_pass_timings(resnmtf_handle* h, resnmtf_pass_timing* out, int reset)
     if (!v.owned) continue;
     const double n = v.n, m = v.m, k = v.k;
     const double sx = v.half ? 2.0 : 4.0;          // bytes per element of X as stored
-    out->xg_bytes = sx * n * m + 4.0 * (n + m) * k;
-    out->xtf_bytes = sx * n * m + 4.0 * (n + m) * k;
+    // (a launch that carries the update of its B operand -- pass_fused_kernel -- also moves that update's algorithmic bytes:
+    //  product rows 4 len k once, the fp64 factor 8 len k in and out, its f32 copy 4 len k out)
+    out->xg_bytes = sx * n * m + 4.0 * (n + m) * k + (can_fuse_update(h, v, 1) ? 24.0 * m * k : 0.0);
+    out->xtf_bytes = sx * n * m + 4.0 * (n + m) * k + (can_fuse_update(h, v, 0) && h->all_owned && h->chain_views == 0 ? 24.0 * n * k : 0.0);
     out->xg_flops = 2.0 * n * m * k;
     out->xtf_flops = 2.0 * n * m * k;
     break;

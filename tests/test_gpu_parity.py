@@ -132,6 +132,31 @@ def test_graph_and_eager_agree_bitwise():
     assert np.array_equal(a["All_Error"], b["All_Error"])
 
 
+@pytest.mark.parametrize("shapes,k,kw", [([(700, 300)], 7, {}), ([(10000, 2000)], 16, {}), ([(3000, 900), (3000, 700)], 12, dict(phi=2.0)),
+                                         ([(900, 5000)], 5, {}), ([(150, 90), (130, 90)], 3, dict(psi=1.0))])
+def test_fused_update_launches_agree_bitwise(shapes, k, kw):
+    """resnmtf_options.fuse_updates (opt-in), k <= 16: an uncoupled update_f / update_g (R/update_steps.r:152-155, :190-193)
+    rides in the first workgroups of the streaming-pass launch that consumes it (pass_fused_kernel; the other workgroups wait
+    on an arrival flag).  Same update code on the same bytes: bitwise the default sweep of separate launches, graph replay and eager, fixed sweeps
+    and convergence mode, consecutive runs.  (phi-coupled views: only the G update is fused; psi-coupled: only F.)"""
+    from resnmtf_amd.engine import Engine
+    prob = synth.make_problem(shapes, k, **kw)
+    outs = {}
+    for key, opts in (("fused", dict(fuse_updates=1)), ("plain", {}), ("fused_eager", dict(fuse_updates=1, use_graph=False)),
+                      ("fused_noprefetch", dict(fuse_updates=2))):
+        e = _engine_for(prob, **opts)
+        errs = np.concatenate([e.run(9), e.run(23)])
+        conv = e.run(None, max_iters=60)
+        outs[key] = (errs, conv, [e.get_factors(v) for v in range(len(shapes))])
+        e.close()
+    for key in ("plain", "fused_eager", "fused_noprefetch"):
+        assert np.array_equal(outs["fused"][0], outs[key][0]) and np.array_equal(outs["fused"][1], outs[key][1])
+        for va, vb in zip(outs["fused"][2], outs[key][2]):
+            for x, y in zip(va, vb):
+                assert np.array_equal(x, y)
+    assert np.isfinite(outs["fused"][0]).all()
+
+
 def test_convergence_mode_matches_oracle():
     """R/main.r:50-81: stop after the first sweep with |d mean err| <= 1e-6."""
     prob = synth.make_problem([(300, 200), (280, 150)], 4)
@@ -224,13 +249,13 @@ def test_full_size_c2_properties():
     assert np.isfinite(lit)
 
 
-def _engine_for(prob):
+def _engine_for(prob, **opts):
     """Engine loaded with a (possibly multi-view, coupled) problem -- the C-ABI call sequence of api.py."""
     from resnmtf_amd import naming
     from resnmtf_amd.engine import Engine
     shapes = [x.shape for x in prob.data]
     n_v = len(shapes)
-    e = Engine([s[0] for s in shapes], [s[1] for s in shapes], [prob.k] * n_v)
+    e = Engine([s[0] for s in shapes], [s[1] for s in shapes], [prob.k] * n_v, **opts)
     for v in range(n_v):
         e.set_view(v, prob.data[v])
         e.set_factors(v, prob.init_f[v], prob.init_s[v], prob.init_g[v])
