@@ -294,7 +294,8 @@ hipError_t set_all_attrs() {
                          reinterpret_cast<const void*>(&pass_fused_kernel<8, false, false>), reinterpret_cast<const void*>(&pass_fused_kernel<8, true, false>),
                          reinterpret_cast<const void*>(&pass_fused_kernel<4, false, false>), reinterpret_cast<const void*>(&pass_fused_kernel<4, true, false>)})
     TRY_ATTR(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-#define S_CHAIN_ATTR(KPV, NVBV) TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&s_chain_kernel<KPV, NVBV>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds))
+  // (s_chain_kernel also holds a static table of NVB x NVB weights: static + dynamic must stay within the CU's LDS)
+#define S_CHAIN_ATTR(KPV, NVBV) TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&s_chain_kernel<KPV, NVBV>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096))
   S_CHAIN_ATTR(16, 4); S_CHAIN_ATTR(16, 8); S_CHAIN_ATTR(16, RESNMTF_MAX_COUPLE + 1);
   S_CHAIN_ATTR(32, 4); S_CHAIN_ATTR(32, 8); S_CHAIN_ATTR(32, RESNMTF_MAX_COUPLE + 1);
   S_CHAIN_ATTR(48, 4); S_CHAIN_ATTR(48, 8); S_CHAIN_ATTR(48, RESNMTF_MAX_COUPLE + 1);
@@ -313,6 +314,13 @@ hipError_t set_all_attrs() {
   SCHAIN_ATTR(48, false, 4); SCHAIN_ATTR(48, true, 4); SCHAIN_ATTR(48, false, 8); SCHAIN_ATTR(48, true, 8);
   SCHAIN_ATTR(64, false, 4); SCHAIN_ATTR(64, true, 4); SCHAIN_ATTR(64, false, 8); SCHAIN_ATTR(64, true, 8);
 #undef SCHAIN_ATTR
+#define SLCHAIN_ATTR(KPV, G, NVBV) TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&slice_chain_kernel<KPV, G, NVBV>), \
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice_chain_smem_bytes(KPV, NVBV)))
+  SLCHAIN_ATTR(16, false, 4); SLCHAIN_ATTR(16, true, 4); SLCHAIN_ATTR(16, false, 8); SLCHAIN_ATTR(16, true, 8);
+  SLCHAIN_ATTR(32, false, 4); SLCHAIN_ATTR(32, true, 4); SLCHAIN_ATTR(32, false, 8); SLCHAIN_ATTR(32, true, 8);
+  SLCHAIN_ATTR(48, false, 4); SLCHAIN_ATTR(48, true, 4); SLCHAIN_ATTR(48, false, 8); SLCHAIN_ATTR(48, true, 8);
+  SLCHAIN_ATTR(64, false, 4); SLCHAIN_ATTR(64, true, 4); SLCHAIN_ATTR(64, false, 8); SLCHAIN_ATTR(64, true, 8);
+#undef SLCHAIN_ATTR
 #define CHAIN_ATTR(NVB, PFV) TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&f_chain_kernel<NVB, PFV>), \
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)f_chain_smem_bytes<NVB>()))
   CHAIN_ATTR(2, 1); CHAIN_ATTR(4, 1); CHAIN_ATTR(8, 1); CHAIN_ATTR(2, 4); CHAIN_ATTR(4, 4); CHAIN_ATTR(8, 4);
@@ -513,8 +521,33 @@ void launch_wide_chain(resnmtf_handle* h, int g, bool checked, bool sliced = fal
   const size_t smem = wide_chain_smem_bytes(KP);
   const int ngrid = sliced ? h->schain_grid[g] : h->wchain_grid[g];
   if (ngrid < 1) return;                                   // (an empty slice)
-  const dim3 grid(ngrid), block(16 * KP);
   const int kind = g == 0 ? RESNMTF_TIMED_F_CHAIN : RESNMTF_TIMED_G_CHAIN;
+  // sliced: the products-first kernel on 16-row groups (slice_chain_kernel); RESNMTF_SLICE_WIDE=1 keeps the view-by-view
+  // walk of wide_chain_kernel on 32-row groups (A/B testing -- same bits either way)
+  // Which of the two: a slice_chain workgroup finishes one 16-row group in ~35 us at k = 64 (latency: 4 product stages + 8
+  // walk steps), a wide_chain workgroup a 32-row group in ~50 us -- so the 16-row form wins while its groups fit ONE round
+  // of resident workgroups (c5 x 8: the G slices, 64 groups; c4 x 4: both chains) and loses when they need two (c5 x 8, F:
+  // 392 groups on 256 CUs, 70 against 53 us).  RESNMTF_SLICE_WIDE=1 / =0 forces one form (A/B testing).
+  static const char* slice_env = std::getenv("RESNMTF_SLICE_WIDE");
+  const int groups16_all = ceil_div(c.len, 16);
+  const int n_slots = h->n_cu * (int)std::max<size_t>(1, std::min<size_t>(kMaxLds / slice_chain_smem_bytes(KP, c.n_views <= 4 ? 4 : 8), 2048 / (16 * KP)));
+  const bool slice_wide = slice_env ? slice_env[0] == '1' : groups16_all > n_slots;
+  if (sliced && !slice_wide) {
+    const int groups16 = ceil_div(c.len, 16);
+    const dim3 grid16(groups16), block16(16 * KP);          // (one row group per workgroup)
+#define SLCHAIN(KPV, NVBV, ARGS) do { const size_t sm = slice_chain_smem_bytes(KPV, NVBV); \
+    if (g == 0) LAUNCH_TIMED(h, kind, (slice_chain_kernel<KPV, false, NVBV>), grid16, block16, sm, ARGS); \
+    else LAUNCH_TIMED(h, kind, (slice_chain_kernel<KPV, true, NVBV>), grid16, block16, sm, ARGS); } while (0)
+#define SLCHAIN_K(NVBV, ARGS) do { \
+    switch (KP) { case 16: SLCHAIN(16, NVBV, ARGS); break; case 32: SLCHAIN(32, NVBV, ARGS); break; \
+                  case 48: SLCHAIN(48, NVBV, ARGS); break; default: SLCHAIN(64, NVBV, ARGS); break; } } while (0)
+    if (c.n_views <= 4) { WideChainArgs<4> a4 = narrow_wchain<4>(c); SLCHAIN_K(4, a4); }
+    else { SLCHAIN_K(8, c); }
+#undef SLCHAIN_K
+#undef SLCHAIN
+    return;
+  }
+  const dim3 grid(ngrid), block(16 * KP);
 #define WCHAIN(KPV, NVBV, ARGS) do { \
     if (sliced) { if (g == 0) LAUNCH_TIMED(h, kind, (wide_chain_kernel<KPV, false, NVBV, true>), grid, block, smem, ARGS); \
                   else LAUNCH_TIMED(h, kind, (wide_chain_kernel<KPV, true, NVBV, true>), grid, block, smem, ARGS); } \
