@@ -307,11 +307,16 @@ class ShardedSweep:
         can_gs = (bool(replicate_f) and self.owner_of == list(range(world)) and len(set(k_all)) == 1 and self.n_views == world)
         self.replicate_gs = bool(can_gs and (gs_coupled if want_gs is None else want_gs))
         # Row-sliced chains instead of replicated ones (one view's worth of chain work per rank instead of V views'): needs the
-        # layout of `sliceable`; chosen by default above k = 16, where a chain step costs more than the two extra exchanges
-        # (the k <= 16 chains of c2-sized views are a few microseconds: one all-gather per sweep beats four all-to-alls)
+        # layout of `sliceable`.  Chosen by default when the chain work it takes off a rank outweighs its three extra
+        # exchanges per sweep (measured on MI355X, tools/time_replica_updates.py: the replicated F + G chains cost ~12 ps per
+        # element and view -- c5 x 8: 321 + 57 us, c4 x 4: 22 + 10 us -- the sliced ones 1 / V of that plus ~30 us of pack /
+        # unpack and latency floors; an exchange ~25 us): c5 x 8 saves ~280 us per sweep and is sliced, c4 x 4 would save
+        # nothing and keeps the replicated chains with their two all-gathers, the small k <= 16 layouts likewise
         can_slice = bool(self.replicate_gs and sliceable(prob, self.owner_of, world) and
                          (engine is None or getattr(engine, "supports_sliced", False)))
-        self.sliced = bool(can_slice and ((k_all[0] > 16) if want_slice is None else want_slice))
+        n0, m0 = prob.init_f[0].shape[0], prob.init_g[0].shape[0]
+        saved_us = 12.0e-6 * self.n_views * (n0 + m0) * k_all[0] * (1.0 - 1.0 / max(self.n_views, 1)) - 30.0
+        self.sliced = bool(can_slice and ((saved_us > 80.0) if want_slice is None else want_slice))
         if want_slice and not self.sliced:
             raise ValueError("slice_chains needs one view per rank (<= 8), equal shapes and k, coupled views sharing all their "
                              "rows / columns in the same order, and coupling that calls for the replicated-chains layout")

@@ -373,7 +373,7 @@ def test_sharded_hip_replicated_g_and_s_chains(tmp_path, world, k):
     """The same layout with the real HIP engine (ranks share the one GPU of the box, gloo): results against the oracle,
     and every rank's copy of every F, G and S bitwise the owner's.  k <= 16: hand-off mode A; k = 24 / 40 / 64: mode B
     (the k x k job of the last-arriving aux workgroup publishes the S block), the wide bf16-piece passes and -- k = 24 / 32 / 57 / 64 --
-    the fused chain launches (wide_chain_kernel; k = 40 has none and takes one launch per view)."""
+    the fused chain launches (wide_chain_kernel; k = 40: its KP = 48 instantiation)."""
     got = launch("gpu_gs", tmp_path, world=world, k=k)
     assert bool(got["mirrors_ok"])
     ref = oracle_reference_gs(world, k=k)
