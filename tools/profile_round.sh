@@ -2,7 +2,7 @@
 #   bench line (driver's flags and the default), rocprofv3 --kernel-trace --stats of the same command, PMC passes
 #   (FETCH_SIZE / WRITE_SIZE / SQ counters: each its own run, --kernel-trace only), the other BASELINE shapes on one GPU,
 #   kernel traces and PMC passes of one c4-sized and one c5-sized view.  Everything lands in gpurun_out/; the summaries
-#   are copied by hand into profiles/ (named per round).
+#   are copied by hand into profiles/ (named per round).  Second call of the session: tools/profile_round_sharded.sh.
 set -e
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -24,4 +24,5 @@ bash tools/profile_cfg.sh c4v1 > /dev/null 2>&1
 bash tools/profile_cfg.sh c5v1 > /dev/null 2>&1
 bash tools/profile_cfg_pmc.sh c4v1 > $O/pmc_c4v1.log 2>&1
 bash tools/profile_cfg_pmc.sh c5v1 > $O/pmc_c5v1.log 2>&1
+python3 tools/make_traffic.py gpurun_out/pmc_fetch2 gpurun_out/pmc_write2 80768000 gpurun_out/traffic_new.json "round 3 final build: tools/profile_round.sh (bench.py --steps 40 --warmup 5, eager launches, separate --pmc FETCH_SIZE / WRITE_SIZE runs)" > /dev/null 2>&1
 echo done
