@@ -199,6 +199,8 @@ def _make_driver(sharded, prob, n_views, rank, world, local_rank, **extra):
                                 **({"replicate_gs": False} if os.environ.get("RESNMTF_NO_REPLICATE_GS") == "1" else {}),
                                 **({"slice_chains": os.environ["RESNMTF_SLICE_CHAINS"] == "1"} if "RESNMTF_SLICE_CHAINS" in os.environ else {}),
                                 **({"overlap_u": False} if os.environ.get("RESNMTF_NO_OVERLAP") == "1" else {}),
+                                # opt-in: the sliced layout's exchanges as peer stores + stream-ordered flags (resnmtf_options.slice_p2p)
+                                **({"slice_p2p": True} if os.environ.get("RESNMTF_P2P") == "1" else {}),
                                 **({"serial_exchange": os.environ["RESNMTF_SERIAL_EXCHANGE"] == "1"}
                                    if "RESNMTF_SERIAL_EXCHANGE" in os.environ else {}), **extra)
 
@@ -334,7 +336,10 @@ def run_sharded(args) -> dict:
                                note=f"ONE of the {n_views} views ({n}x{m}, k={k}; coupling terms left out: O(n k) beside the four X passes)")
         except Exception as exc:
             print(f"[bench] cpu baseline failed: {exc}", file=sys.stderr)
-    layout = (("F and G chains ROW-SLICED over the ranks (all-to-all of row slices), S chain replicated; "
+    layout = (("F and G chains ROW-SLICED over the ranks, S chain replicated; exchange by peer stores into the receivers' buffers (hipIpc / xGMI) "
+               "ordered by stream-waited arrival counters, no collective in the sweep")
+              if (sliced and per_sweep == 0) else
+              ("F and G chains ROW-SLICED over the ranks (all-to-all of row slices), S chain replicated; "
                f"{per_sweep} collectives per sweep between dependent steps" + (", U slices on a second communicator beside the S chain" if overlapped else ""))
               if sliced else
               ("F, G and S chains replicated on every rank, " + ("two" if per_sweep == 2 else "three") + " block all-gathers per sweep") if replicated_gs else

@@ -175,6 +175,16 @@ typedef struct resnmtf_options {
                              hand-off mode B is used at every k.  Otherwise fall back to replicate_gs. */
   int slice_index;        /* which slice this handle walks (= the rank) */
   int slice_count;        /* number of slices (= ranks = views) */
+  int slice_p2p;          /* with slice_chains (opt-in): the four exchanges of a sweep as PEER STORES + stream-ordered flags instead
+                             of collectives -- the chain kernels and slice_pack_kernel store their output straight into the
+                             receiving rank's buffers (mapped through hipIpc: xGMI peer access across GPUs), a one-wave kernel then
+                             adds one arrival to every rank's counter of that exchange, and the consuming phase begins with a
+                             hipStreamWaitValue32 for the V arrivals of its sweep: no collective launch, no host in the loop, no
+                             device-side spin.  Set-up: resnmtf_p2p_export on every rank, the handles exchanged by the host
+                             (any channel), resnmtf_p2p_import for every rank (the own one included), a host barrier, then ONE
+                             resnmtf_prepare.  Receive buffers are single: the order of the sweep itself keeps a writer one
+                             exchange behind its reader.  Tested with 2-4 processes on one GPU (IPC on one
+                             device); not yet run across GPUs */
   int fuse_updates;       /* 0 (default): every factor update is a launch of its own.  1 / 2 (opt-in, k <= 16, hand-off mode A, f32
                              images): an UNCOUPLED update_f / update_g (R/update_steps.r:152-155 / :190-193) runs in the first
                              workgroups of the Xt.F / X.G' launch that consumes it, the other workgroups wait for it on an arrival
@@ -378,6 +388,10 @@ int resnmtf_kernel_timings(resnmtf_handle* h, double* ms_total, long long* launc
  * which it fired (any pointer may be NULL). */
 int resnmtf_set_stop_tolerance(resnmtf_handle* h, double tol);
 int resnmtf_loop_state(resnmtf_handle* h, int* sweeps_done, int* done, int* stop_sweep);
+/* slice_p2p: the IPC handles of this handle's receive buffers and arrival counters (6 x 64 bytes; *bytes receives the size) /
+ * map rank `rank`'s (for the own rank `handles` is ignored).  After every rank is imported the slice phases store to the peers. */
+int resnmtf_p2p_export(resnmtf_handle* h, void* handles, size_t capacity, size_t* bytes);
+int resnmtf_p2p_import(resnmtf_handle* h, int rank, const void* handles, size_t bytes);
 /* slice_chains: rows / columns per slice (multiples of 32; slice r covers [r * per_slice, min((r + 1) * per_slice, n))). */
 int resnmtf_slice_info(resnmtf_handle* h, int* rows_per_slice, int* cols_per_slice);
 

@@ -41,7 +41,7 @@ class Options(C.Structure):
         ("no_pitch_pad", C.c_int), ("kk_mode", C.c_int), ("bf16_split", C.c_int), ("replicate_f", C.c_int),
         ("no_f_chain", C.c_int), ("x_half", C.c_int), ("half_unroll", C.c_int), ("replicate_gs", C.c_int),
         ("wait_mode", C.c_int), ("slice_chains", C.c_int), ("slice_index", C.c_int), ("slice_count", C.c_int),
-        ("fuse_updates", C.c_int),
+        ("slice_p2p", C.c_int), ("fuse_updates", C.c_int),
     ]
 
 
@@ -93,6 +93,8 @@ SIGNATURES = {
     "resnmtf_set_stop_tolerance": (C.c_int, [_h, C.c_double]),
     "resnmtf_loop_state": (C.c_int, [_h, _ip, _ip, _ip]),
     "resnmtf_slice_info": (C.c_int, [_h, _ip, _ip]),
+    "resnmtf_p2p_export": (C.c_int, [_h, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "resnmtf_p2p_import": (C.c_int, [_h, C.c_int, C.c_void_p, C.c_size_t]),
 }
 
 _lib = None

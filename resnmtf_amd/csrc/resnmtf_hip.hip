@@ -143,6 +143,14 @@ struct resnmtf_handle {
   char *u_send = nullptr, *u_recv = nullptr, *t_send = nullptr, *t_recv = nullptr;
   size_t u_chunk = 0, t_chunk = 0;    // bytes per chunk: [per_slice][KP] f32 (+ the fp64 tail Ma_G | Md_G for T)
   float *f_send = nullptr, *f_recv = nullptr, *g_send = nullptr, *g_recv = nullptr;      // [V][per_slice][KP] f32 each
+  // slice_p2p: the exchange as peer stores + stream-ordered flags (no collective): every rank's receive buffers and flag words,
+  // mapped through hipIpc (own rank: the local pointers); flags[e] counts the arrivals of exchange e (0 U + S blocks, 1 new F
+  // rows, 2 T slices, 3 new G rows): V per sweep
+  struct Peer { char *u_recv = nullptr, *t_recv = nullptr; float *f_recv = nullptr, *g_recv = nullptr; double* sblk = nullptr;
+                unsigned int* flags = nullptr; bool imported = false; void* opened[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; };
+  std::vector<Peer> peers;
+  unsigned int* p2p_flags = nullptr;
+  bool p2p_ready = false, p2p_prepared = false;
   WideChainArgs<8> schain[2]{};       // SLICE_F ([0]) / SLICE_G ([1])
   int schain_grid[2] = {0, 0};
   double ktime_ms[RESNMTF_TIMED_KINDS] = {0, 0, 0, 0, 0, 0};     // time_kernels: per kind (resnmtf_kernel_timings)
@@ -506,7 +514,7 @@ WideChainArgs<NVB> narrow_wchain(const WideChainArgs<8>& c) {
   a.len = c.len; a.k = c.k; a.n_views = c.n_views; a.ngroups = c.ngroups; a.own = c.own; a.n_self = c.n_self; a.O32 = c.O32; a.o32_stride = c.o32_stride;
   a.W32 = c.W32; a.Wk = c.Wk; a.T32 = c.T32; a.ld32 = c.ld32; a.ctl = c.ctl; a.check_done = c.check_done; a.restricted = c.restricted;
   for (int v = 0; v < NVB; ++v) {
-    a.W[v] = c.W[v]; a.U[v] = c.U[v]; a.Ma[v] = c.Ma[v]; a.Md[v] = c.Md[v]; a.lm[v] = c.lm[v];
+    a.W[v] = c.W[v]; a.U[v] = c.U[v]; a.Ma[v] = c.Ma[v]; a.Md[v] = c.Md[v]; a.lm[v] = c.lm[v]; a.O32v[v] = c.O32v[v];
     a.sigma[v] = c.sigma[v]; a.n_other[v] = c.n_other[v]; a.cmask[v] = c.cmask[v];
     for (int w = 0; w < NVB; ++w) a.weight[v][w] = c.weight[v][w];
   }
@@ -615,9 +623,30 @@ void launch_slice_pack(resnmtf_handle* h, const ViewState& v, bool xg, bool chec
   a.rows_per_slice = xg ? h->sl_rows : h->sl_cols; a.n_slices = h->opt.slice_count;
   a.out = xg ? h->u_send : h->t_send; a.chunk_bytes = xg ? h->u_chunk : h->t_chunk;
   if (!xg) { a.tail[0] = v.Ma_G; a.tail[1] = v.Md_G; a.tail_count = v.k * v.k; a.T32 = v.T32; a.ld32 = 64; }
+  if (h->opt.slice_p2p) {      // chunk c straight into rank c's receive slot for this rank; U: the own S block into every rank's arena
+    const int r = h->opt.slice_index, vi = (int)(&v - h->views.data());
+    a.out = nullptr;
+    for (int c = 0; c < a.n_slices; ++c) {
+      const resnmtf_handle::Peer& pc = h->peers[(size_t)c];
+      a.outv[c] = (xg ? pc.u_recv : pc.t_recv) + (size_t)r * a.chunk_bytes;
+      if (xg) a.tailv[c] = pc.sblk + (size_t)vi * h->sblk_stride;
+    }
+    if (xg) { a.tail[0] = v.sblk; a.tail[1] = v.sblk + h->sblk_stride / 2; a.tail_count = (int)(h->sblk_stride / 2); }
+  }
   a.ctl = h->ctl; a.check_done = checked ? 1 : 0;
   const size_t quads = (size_t)a.n_slices * a.rows_per_slice * (a.KP / 4);
   LAUNCH_TIMED(h, RESNMTF_TIMED_PACK, slice_pack_kernel, dim3((unsigned)std::min<size_t>((quads + 255) / 256, 65535)), dim3(256), 0, a);
+}
+// slice_p2p: one arrival on every rank's counter of exchange e (stream-ordered behind the kernels that stored the data) /
+// the stream waits until `arrivals` of them are in
+void p2p_signal(resnmtf_handle* h, int e) {
+  SliceSignalArgs a{};
+  a.n = h->V;
+  for (int c = 0; c < h->V; ++c) a.flag[c] = h->peers[(size_t)c].flags + e;
+  hipLaunchKernelGGL(slice_signal_kernel, dim3(1), dim3(64), 0, h->stream, a);
+}
+hipError_t p2p_wait(resnmtf_handle* h, int e, unsigned int arrivals) {
+  return hipStreamWaitValue32(h->stream, h->p2p_flags + e, arrivals, hipStreamWaitValueGte, 0xFFFFFFFFu);
 }
 // slice_chains: the own view's new F (g == 0) / G (g == 1) rows, as received, -> the operand copies of the next pass
 void launch_slice_unpack(resnmtf_handle* h, const ViewState& v, int g, bool checked) {
@@ -687,6 +716,7 @@ void enqueue_prologue(resnmtf_handle* h, const ViewState& v) {
   launch_pass(h, v, true, 0, -1.0, false);
   launch_fold(h, v);
   if (h->sliced) launch_slice_pack(h, v, true, false);
+  if (h->sliced && h->opt.slice_p2p) p2p_signal(h, 0);
 }
 
 void enqueue_sweep(resnmtf_handle* h, double tol) {
@@ -1012,6 +1042,7 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
       }
     if (why) { g_create_error = why; return RESNMTF_ERR_INVALID; }
   }
+  if (o.slice_p2p && !o.slice_chains) { g_create_error = "slice_p2p needs slice_chains"; return RESNMTF_ERR_INVALID; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
     g_create_error = "no HIP device available (this library has no CPU fallback)";
@@ -1130,6 +1161,13 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     if ((e = dev_alloc_zero(&h->f_recv, (size_t)V * h->sl_rows * v0.KP)) != hipSuccess) return bail(e, "hipMalloc slice exchange buffers");
     if ((e = dev_alloc_zero(&h->g_send, (size_t)V * h->sl_cols * v0.KP)) != hipSuccess) return bail(e, "hipMalloc slice exchange buffers");
     if ((e = dev_alloc_zero(&h->g_recv, (size_t)V * h->sl_cols * v0.KP)) != hipSuccess) return bail(e, "hipMalloc slice exchange buffers");
+    if (o.slice_p2p) {
+      int can = 0;
+      (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, o.device_id);
+      if (!can) { g_create_error = "slice_p2p needs hipStreamWaitValue32 (hipDeviceAttributeCanUseStreamWaitValue)"; resnmtf_destroy(h); return RESNMTF_ERR_NO_DEVICE; }
+      if ((e = dev_alloc_zero(&h->p2p_flags, 64)) != hipSuccess) return bail(e, "hipMalloc p2p flags");
+      h->peers.resize((size_t)V);
+    }
   }
   size_t fblk_off = 0, gblk_off = 0;
   for (int v = 0; v < n_views; ++v) {
@@ -1291,7 +1329,10 @@ int resnmtf_destroy(resnmtf_handle* h) {
   if (h->fblk_arena) (void)hipFree(h->fblk_arena);
   if (h->gblk_arena) (void)hipFree(h->gblk_arena);
   if (h->sblk_arena) (void)hipFree(h->sblk_arena);
-  for (void* p : {(void*)h->view_sweep, (void*)h->u_send, (void*)h->u_recv, (void*)h->t_send, (void*)h->t_recv, (void*)h->f_send,
+  for (auto& pc : h->peers)
+    for (void* q : pc.opened)
+      if (q) (void)hipIpcCloseMemHandle(q);
+  for (void* p : {(void*)h->p2p_flags, (void*)h->view_sweep, (void*)h->u_send, (void*)h->u_recv, (void*)h->t_send, (void*)h->t_recv, (void*)h->f_send,
                   (void*)h->f_recv, (void*)h->g_send, (void*)h->g_recv})
     if (p) (void)hipFree(p);
   if (h->ctl) (void)hipFree(h->ctl);
@@ -2038,6 +2079,11 @@ static int build_slice_chain(resnmtf_handle* h) {
           if (u.couple[c].W == (g == 0 ? h->views[w].F : h->views[w].G)) { a.cmask[v] |= 1u << w; a.weight[v][w] = u.couple[c].weight; }
     }
     a.O32 = g == 0 ? h->f_send : h->g_send; a.o32_stride = (unsigned)((size_t)per * v0.KP);
+    if (h->opt.slice_p2p) {      // straight into the owner's receive slot for this rank's slice
+      if (!h->p2p_ready) return h->fail(RESNMTF_ERR_STATE, "slice_p2p: import every rank's buffers first (resnmtf_p2p_import)");
+      a.O32 = nullptr;
+      for (int v = 0; v < V; ++v) a.O32v[v] = (g == 0 ? h->peers[(size_t)v].f_recv : h->peers[(size_t)v].g_recv) + (size_t)r * per * v0.KP;
+    }
     a.len = len; a.n_self = full; a.k = v0.k; a.n_views = V; a.ngroups = ceil_div(std::max(len, 0), 32);
     a.ctl = h->ctl;
     h->schain_grid[g] = std::min(a.ngroups, h->n_cu * (v0.KP <= 32 ? 2 : 1));
@@ -2207,6 +2253,11 @@ int resnmtf_prepare(resnmtf_handle* h) {
   if (!h) return RESNMTF_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
   if (int rc = sync_both(h)) return rc;
+  if (h->opt.slice_p2p) {      // the arrival counters only count up: one prepare per handle (the driver prepares once)
+    if (!h->p2p_ready) return h->fail(RESNMTF_ERR_STATE, "slice_p2p: import every rank's buffers first (resnmtf_p2p_import)");
+    if (h->p2p_prepared) return h->fail(RESNMTF_ERR_STATE, "slice_p2p: a handle is prepared once (its arrival counters are cumulative)");
+    h->p2p_prepared = true;
+  }
   return prepare_impl(h, false);
 }
 
@@ -2252,20 +2303,36 @@ int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep) {
         if (w.owned || w.g_replica) launch_update(h, w, 1, checked);
       break;
     case RESNMTF_PHASE_XG: launch_pass(h, vs, true, 1, tol, checked); launch_fold(h, vs); break;
+    // slice_p2p: every phase first waits (in stream order, hipStreamWaitValue32) until the V arrivals of the exchange that
+    // feeds it are in, and ends with one arrival on every rank's counter of the exchange it fed with peer stores.
+    // Arrivals so far: U + S blocks V (t + 2) after sweep t's X.G (the run prologue is the first), the others V (t + 1).
     case RESNMTF_PHASE_S_ALL:
+      if (h->opt.slice_p2p) HIP_TRY(h, p2p_wait(h, 0, (unsigned)h->V * (unsigned)(sweep + 2)));
       if (int rc = launch_s_chain(h, checked)) return rc;
       break;
-    case RESNMTF_PHASE_SLICE_F: launch_wide_chain(h, 0, checked, true); break;
+    case RESNMTF_PHASE_SLICE_F:
+      if (h->opt.slice_p2p) HIP_TRY(h, p2p_wait(h, 0, (unsigned)h->V * (unsigned)(sweep + 1)));
+      launch_wide_chain(h, 0, checked, true);
+      if (h->opt.slice_p2p) p2p_signal(h, 1);
+      break;
     case RESNMTF_PHASE_SLICE_XTF:
+      if (h->opt.slice_p2p) HIP_TRY(h, p2p_wait(h, 1, (unsigned)h->V * (unsigned)(sweep + 1)));
       launch_slice_unpack(h, vs, 0, checked);
       launch_pass(h, vs, false, 1, tol, checked);
       launch_slice_pack(h, vs, false, checked);
+      if (h->opt.slice_p2p) p2p_signal(h, 2);
       break;
-    case RESNMTF_PHASE_SLICE_G: launch_wide_chain(h, 1, checked, true); break;
+    case RESNMTF_PHASE_SLICE_G:
+      if (h->opt.slice_p2p) HIP_TRY(h, p2p_wait(h, 2, (unsigned)h->V * (unsigned)(sweep + 1)));
+      launch_wide_chain(h, 1, checked, true);
+      if (h->opt.slice_p2p) p2p_signal(h, 3);
+      break;
     case RESNMTF_PHASE_SLICE_XG:
+      if (h->opt.slice_p2p) HIP_TRY(h, p2p_wait(h, 3, (unsigned)h->V * (unsigned)(sweep + 1)));
       launch_slice_unpack(h, vs, 1, checked);
       launch_pass(h, vs, true, 1, tol, checked);
       launch_slice_pack(h, vs, true, checked);
+      if (h->opt.slice_p2p) p2p_signal(h, 0);
       break;
     default: return h->fail(RESNMTF_ERR_INVALID, "unknown phase");
   }
@@ -2547,6 +2614,46 @@ int resnmtf_slice_info(resnmtf_handle* h, int* rows_per_slice, int* cols_per_sli
   if (!h->sliced) return h->fail(RESNMTF_ERR_STATE, "not a slice_chains handle");
   if (rows_per_slice) *rows_per_slice = h->sl_rows;
   if (cols_per_slice) *cols_per_slice = h->sl_cols;
+  return RESNMTF_OK;
+}
+
+int resnmtf_p2p_export(resnmtf_handle* h, void* handles, size_t capacity, size_t* bytes) {
+  if (!h || !bytes) return RESNMTF_ERR_INVALID;
+  if (!h->opt.slice_p2p) return h->fail(RESNMTF_ERR_STATE, "not a slice_p2p handle");
+  *bytes = 6 * sizeof(hipIpcMemHandle_t);
+  if (!handles || capacity < *bytes) return h->fail(RESNMTF_ERR_INVALID, "handle buffer too small");
+  HIP_TRY(h, hipSetDevice(h->opt.device_id));
+  void* bufs[6] = {h->u_recv, h->f_recv, h->t_recv, h->g_recv, h->sblk_arena, h->p2p_flags};
+  auto* out = static_cast<hipIpcMemHandle_t*>(handles);
+  for (int b = 0; b < 6; ++b) HIP_TRY(h, hipIpcGetMemHandle(&out[b], bufs[b]));
+  return RESNMTF_OK;
+}
+
+int resnmtf_p2p_import(resnmtf_handle* h, int rank, const void* handles, size_t bytes) {
+  if (!h) return RESNMTF_ERR_INVALID;
+  if (!h->opt.slice_p2p) return h->fail(RESNMTF_ERR_STATE, "not a slice_p2p handle");
+  if (rank < 0 || rank >= h->V) return h->fail(RESNMTF_ERR_INVALID, "rank out of range");
+  resnmtf_handle::Peer& pc = h->peers[(size_t)rank];
+  if (pc.imported) return h->fail(RESNMTF_ERR_STATE, "rank already imported");
+  HIP_TRY(h, hipSetDevice(h->opt.device_id));
+  void* ptr[6];
+  if (rank == h->opt.slice_index) {
+    void* own[6] = {h->u_recv, h->f_recv, h->t_recv, h->g_recv, h->sblk_arena, h->p2p_flags};
+    for (int b = 0; b < 6; ++b) ptr[b] = own[b];
+  } else {
+    if (!handles || bytes < 6 * sizeof(hipIpcMemHandle_t)) return h->fail(RESNMTF_ERR_INVALID, "handle buffer too small");
+    const auto* in = static_cast<const hipIpcMemHandle_t*>(handles);
+    for (int b = 0; b < 6; ++b) {
+      HIP_TRY(h, hipIpcOpenMemHandle(&ptr[b], in[b], hipIpcMemLazyEnablePeerAccess));
+      pc.opened[b] = ptr[b];
+    }
+  }
+  pc.u_recv = static_cast<char*>(ptr[0]); pc.f_recv = static_cast<float*>(ptr[1]); pc.t_recv = static_cast<char*>(ptr[2]);
+  pc.g_recv = static_cast<float*>(ptr[3]); pc.sblk = static_cast<double*>(ptr[4]); pc.flags = static_cast<unsigned int*>(ptr[5]);
+  pc.imported = true;
+  h->p2p_ready = true;
+  for (const auto& q : h->peers) h->p2p_ready = h->p2p_ready && q.imported;
+  h->prepared = false;
   return RESNMTF_OK;
 }
 

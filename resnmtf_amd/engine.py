@@ -42,7 +42,7 @@ class Engine:
                  pass_splits_xtf: int = 0, pass_lds_pad_kb: int = 0, update_blocks: int = 0, no_pitch_pad: bool = False,
                  kk_mode: int = 0, bf16_split: int = 0, replicate_f: bool = False, no_f_chain: bool = False,
                  x_half: int = 0, half_unroll: int = 0, replicate_gs: bool = False, wait_mode: int = 0,
-                 slice_chains: bool = False, slice_index: int = 0, slice_count: int = 0, fuse_updates: int = 0):
+                 slice_chains: bool = False, slice_index: int = 0, slice_count: int = 0, fuse_updates: int = 0, slice_p2p: bool = False):
         self._lib = _lib.load()
         self.n_views = len(n_rows)
         self.n_rows = [int(x) for x in n_rows]
@@ -75,6 +75,7 @@ class Engine:
         opts.slice_index = int(slice_index)
         opts.slice_count = int(slice_count)
         opts.fuse_updates = int(fuse_updates)
+        opts.slice_p2p = 1 if slice_p2p else 0
         nr = np.asarray(self.n_rows, dtype=np.int32)
         nc = np.asarray(self.n_cols, dtype=np.int32)
         kk = np.asarray(self.k, dtype=np.int32)
@@ -273,6 +274,17 @@ class Engine:
         a, b = C.c_int(0), C.c_int(0)
         self._check(self._lib.resnmtf_slice_info(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def p2p_export(self) -> bytes:
+        """slice_p2p: the IPC handles of this engine's receive buffers and arrival counters (opaque bytes for the peers)."""
+        buf = C.create_string_buffer(1024)
+        n = C.c_size_t(0)
+        self._check(self._lib.resnmtf_p2p_export(self._h, buf, 1024, C.byref(n)))
+        return buf.raw[:n.value]
+
+    def p2p_import(self, rank: int, handles: bytes = b""):
+        buf = C.create_string_buffer(handles, max(len(handles), 1))
+        self._check(self._lib.resnmtf_p2p_import(self._h, int(rank), buf, len(handles)))
 
     def kernel_timings(self, reset: bool = False) -> dict:
         """time_kernels: {kind: (ms_total, launches)} for the kernels of a view-sharded sweep."""

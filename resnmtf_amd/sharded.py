@@ -159,6 +159,12 @@ class HipEngineAdapter:
     def kernel_timings(self, reset=False):
         return self.e.kernel_timings(reset)
 
+    def p2p_export(self):
+        return self.e.p2p_export()
+
+    def p2p_import(self, rank, handles=b""):
+        self.e.p2p_import(rank, handles)
+
     def __init__(self, engine):
         self.e = engine
         self._views: Dict[tuple, object] = {}
@@ -301,6 +307,7 @@ class ShardedSweep:
         # (G_v' needs G_w' of every w < v, R/update_steps.r:195-204; S likewise, :231-237)
         want_gs = engine_opts.pop("replicate_gs", None)
         want_slice = engine_opts.pop("slice_chains", None)
+        self.p2p = bool(engine_opts.pop("slice_p2p", False))
         self._overlap_u = bool(engine_opts.pop("overlap_u", True))
         gs_coupled = any(p["G"] or p["S"] for p in self.plan)
         k_all = [f.shape[1] for f in prob.init_f]
@@ -344,8 +351,10 @@ class ShardedSweep:
             torch.cuda.set_device(device_index)
             self._tstream = torch.cuda.Stream(device=device_index)
             self._xstream = self._tstream if self._serial else torch.cuda.Stream(device=device_index)
+            if self.p2p and not self.sliced:
+                raise ValueError("slice_p2p is an exchange form of the sliced-chains layout")
             if self.sliced:
-                engine_opts = dict(engine_opts, slice_chains=True, slice_index=rank, slice_count=world)
+                engine_opts = dict(engine_opts, slice_chains=True, slice_index=rank, slice_count=world, slice_p2p=self.p2p)
             self.engine = make_hip_engine(prob, self.owned, device_index, self._tstream.cuda_stream,
                                           replicate_f=any(self.replicated), replicate_gs=self.replicate_gs, **engine_opts)
         self.sweeps_done = 0
@@ -364,7 +373,19 @@ class ShardedSweep:
         self._ustream = None
         self._ev_u = self._ev_xg = None
         self._collected = True
-        if self.sliced and self._tstream is not None and self._overlap_u and dist.get_backend(group) == "nccl":
+        if self.sliced and self.p2p:
+            # peer stores + stream-ordered flags instead of collectives (resnmtf_options.slice_p2p): every rank maps every
+            # rank's receive buffers (hipIpc; the handles travel as objects over the process group, once), then a barrier --
+            # nobody signals before everybody has mapped and zeroed
+            if self._tstream is None or not hasattr(self.engine, "p2p_export"):
+                raise ValueError("slice_p2p needs the HIP engine")
+            mine = self.engine.p2p_export()
+            everyone: List[Optional[bytes]] = [None] * world
+            dist.all_gather_object(everyone, mine, group=group)
+            for r in range(world):
+                self.engine.p2p_import(r, b"" if r == rank else everyone[r])
+            dist.barrier(group=group)
+        elif self.sliced and self._tstream is not None and self._overlap_u and dist.get_backend(group) == "nccl":
             import torch
             self._group_u = dist.new_group(ranks=list(range(world)), backend="nccl")      # collective: every rank gets here
             self._ustream = torch.cuda.Stream(device=device_index)
@@ -398,6 +419,8 @@ class ShardedSweep:
     @property
     def collectives_per_sweep(self) -> int:
         """Collectives between dependent steps of one sweep in the replicated-chains layouts (0: ordered broadcasts)."""
+        if self.sliced and self.p2p:
+            return 0             # peer stores + stream-ordered flags
         if self.sliced:          # F rows back, T slices, G rows back, S blocks (+ the U slices beside the S chain when overlapped)
             return 4 if self._group_u is not None else 5
         if self.replicate_gs:
@@ -506,6 +529,10 @@ class ShardedSweep:
             -> operand copies, X.G' pass of the own view + first half of its k x k job
             -> [S blocks] -> S chain, lambda, mu, error, F coefficients of every view    ||   [U row slices]  (beside it)"""
         r, e = self.rank, self.engine
+        if self.p2p:         # the phases store to the peers and wait for their own arrivals in stream order: nothing to do here
+            for ph in (PHASE_SLICE_F, PHASE_SLICE_XTF, PHASE_SLICE_G, PHASE_SLICE_XG, PHASE_S_ALL):
+                e.phase(r, ph, t)
+            return
         if self._group_u is not None:
             self._tstream.wait_event(self._ev_u)             # this sweep's F chain reads the U slices
         e.phase(r, PHASE_SLICE_F, t)
@@ -686,8 +713,8 @@ class ShardedSweep:
             if self.replicate_gs:         # F blocks (U, coefficients, lambda) and G blocks (mu of every view)
                 self._gather_blocks("FBLOCK")
                 self._gather_blocks("GBLOCK")
-                if self.sliced:           # ... and every view's U rows of my slice (the run prologue packed them)
-                    self._exchange_u()
+                if self.sliced and not self.p2p:      # ... and every view's U rows of my slice (the run prologue packed them;
+                    self._exchange_u()                 #     slice_p2p: it stored them to the peers itself)
             elif any(self.replicated):    # the run prologue filled the owners' blocks: hand them round once
                 if self._tstream is not None and self._xstream is not self._tstream:
                     self._ev_g = self._next_event()
@@ -772,4 +799,8 @@ class ShardedSweep:
         return {k: [out[v][i] for v in range(self.n_views)] for i, k in enumerate(keys)}
 
     def close(self):
+        if self.p2p:             # peers may still be storing into this rank's buffers / reading its flags
+            if self._tstream is not None:
+                self.engine.synchronize()
+            self.dist.barrier(group=self.group)
         self.engine.close()

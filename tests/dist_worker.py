@@ -467,7 +467,8 @@ def main():
     ap.add_argument("--world", type=int, required=True)
     ap.add_argument("--port", type=int, required=True)
     ap.add_argument("--mode", choices=["cpu", "cpu_gs", "gpu", "gpu_gs", "gpu_norep", "gpu_allgather", "gpu_chain", "gpu_chain_off", "gpu_graph1", "gpu_gs_rccl1",
-                                       "cpu_slice", "cpu_slice_conv", "gpu_slice", "gpu_slice_conv", "gpu_gs_conv", "gpu_slice_rccl1", "gpu_gs_graph1"], required=True)
+                                       "cpu_slice", "cpu_slice_conv", "gpu_slice", "gpu_slice_conv", "gpu_gs_conv", "gpu_slice_rccl1", "gpu_gs_graph1",
+                                       "gpu_slice_p2p", "gpu_slice_p2p_conv"], required=True)
     ap.add_argument("--n", type=int, default=96)
     ap.add_argument("--m", type=int, default=72)
     ap.add_argument("--tol", type=float, default=1e-6)
@@ -556,7 +557,7 @@ def main():
         dist.destroy_process_group()
         return
     dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
-    if a.mode in ("cpu_slice", "cpu_slice_conv", "gpu_slice", "gpu_slice_conv", "gpu_gs_conv"):
+    if a.mode in ("cpu_slice", "cpu_slice_conv", "gpu_slice", "gpu_slice_conv", "gpu_gs_conv", "gpu_slice_p2p", "gpu_slice_p2p_conv"):
         slice_main(a, dist, sharded)
         return
     one_per_rank = a.mode in ("gpu_allgather", "gpu_chain", "gpu_chain_off")
@@ -628,8 +629,10 @@ def slice_main(a, dist, sharded):
             raw = b"".join(drv.engine.factor_tensor(a.rank, kd).cpu().numpy().tobytes() for kd in ("F", "G", "S"))
         return errs, res, raw
 
-    drv = make(a.mode != "gpu_gs_conv", kk_mode=2)
-    assert drv.sliced == (a.mode != "gpu_gs_conv") and drv.replicate_gs
+    p2p = "p2p" in a.mode
+    drv = make(a.mode != "gpu_gs_conv", kk_mode=2, **({"slice_p2p": True} if p2p else {}))
+    assert drv.sliced == (a.mode != "gpu_gs_conv") and drv.replicate_gs and drv.p2p == p2p
+    assert not p2p or drv.collectives_per_sweep == 0
     if conv:
         done = drv.run(None, tol=a.tol, max_iters=a.sweeps, check_every=7)
         extra["sweeps_done"] = np.array(done)
@@ -641,9 +644,9 @@ def slice_main(a, dist, sharded):
         drv.run(a.sweeps - a.sweeps // 2)          # two calls: state carries over
     errs, res, raw = results(drv)
     drv.close()
-    if a.mode == "gpu_slice":                      # the same run with the chains REPLICATED (same hand-off mode): bitwise
-        drv2 = make(False, kk_mode=2)
-        assert not drv2.sliced and drv2.replicate_gs
+    if a.mode in ("gpu_slice", "gpu_slice_p2p"):   # the same run with the chains REPLICATED (same hand-off mode) / p2p: with the
+        drv2 = make(a.mode == "gpu_slice_p2p", kk_mode=2)      # all-to-all exchange (gloo here): bitwise
+        assert drv2.sliced == (a.mode == "gpu_slice_p2p") and drv2.replicate_gs and not drv2.p2p
         drv2.run(a.sweeps // 2)
         drv2.run(a.sweeps - a.sweeps // 2)
         errs2, res2, raw2 = results(drv2)

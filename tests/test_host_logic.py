@@ -81,7 +81,7 @@ def test_library_loads_and_exports_header_symbols():
     from resnmtf_amd import _lib
     lib = _lib.load()
     header = open(os.path.join(ROOT, "include", "resnmtf_hip.h")).read()
-    declared = set(re.findall(r"\b(resnmtf_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(resnmtf_[a-z0-9_]+)\s*\(", header))
     assert declared, "no declarations found"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:

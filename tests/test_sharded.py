@@ -498,3 +498,31 @@ def test_replicated_gs_graph_chunk_one_rank_rccl(tmp_path):
     got = launch("gpu_gs_graph1", tmp_path, world=1, sweeps=19, k=7)
     assert bool(got["same"])
     assert len(got["all_error"]) == 19 and np.isfinite(got["all_error"]).all() and got["all_error"][-1] != got["all_error"][0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,k,n,m", [(2, 16, 700, 200), (3, 40, 301, 97), (4, 64, 1000, 330), (4, 57, 90, 64)])
+def test_sharded_hip_sliced_chains_peer_stores(tmp_path, world, k, n, m):
+    """resnmtf_options.slice_p2p: the four exchanges of a sliced sweep as PEER STORES into the receiving rank's buffers (mapped
+    through hipIpc -- here between processes on one GPU; xGMI peer access across GPUs) ordered by arrival counters the consumer's
+    stream waits on (hipStreamWaitValue32): no collective in the sweep.  Results against the oracle and BITWISE those of the
+    all-to-all exchange; single receive buffers, ragged and empty slices."""
+    got = launch("gpu_slice_p2p", tmp_path, world=world, k=k, sweeps=14, extra=("--n", n, "--m", m))
+    assert bool(got["bitwise_vs_replicated"])
+    ref = oracle_reference_slice(world, sweeps=14, k=k, n=n, m=m)
+    np.testing.assert_allclose(got["all_error"], ref["All_Error"], atol=2e-5, rtol=1e-4)
+    for v in range(world):
+        assert rel_fro(got[f"output_f{v}"], ref["output_f"][v]) < 2e-5
+        assert rel_fro(got[f"output_g{v}"], ref["output_g"][v]) < 2e-5
+        assert rel_fro(got[f"output_s{v}"], ref["output_s"][v]) < 1e-4
+
+
+@pytest.mark.gpu
+def test_sharded_hip_peer_stores_convergence_mode(tmp_path):
+    """Convergence mode with the peer-store exchange: the arrival counters keep counting through the sweeps enqueued after
+    the stop test fired (their kernels return at once, their signals still go out), all ranks stop on the same sweep."""
+    got = launch("gpu_slice_p2p_conv", tmp_path, world=3, k=24, sweeps=600, extra=("--n", 333, "--m", 161, "--tol", 1e-6))
+    ref = oracle_reference_slice(3, k=24, n=333, m=161, max_iters=600)
+    assert bool(got["same_stop"])
+    done = int(got["sweeps_done"])
+    assert done < 600 and abs(done - len(ref["All_Error"])) <= 2, (done, len(ref["All_Error"]))
