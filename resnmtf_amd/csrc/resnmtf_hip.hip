@@ -1165,7 +1165,14 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
       int can = 0;
       (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, o.device_id);
       if (!can) { g_create_error = "slice_p2p needs hipStreamWaitValue32 (hipDeviceAttributeCanUseStreamWaitValue)"; resnmtf_destroy(h); return RESNMTF_ERR_NO_DEVICE; }
-      if ((e = dev_alloc_zero(&h->p2p_flags, 64)) != hipSuccess) return bail(e, "hipMalloc p2p flags");
+      // the arrival counters are written by other devices' atomics and polled by this device's command processor: fine-grained
+      // (coherent) memory where the runtime offers it
+      if (hipExtMallocWithFlags(reinterpret_cast<void**>(&h->p2p_flags), 64 * sizeof(unsigned int), hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        h->p2p_flags = nullptr;
+        if ((e = hipMalloc(reinterpret_cast<void**>(&h->p2p_flags), 64 * sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMalloc p2p flags");
+      }
+      if ((e = hipMemset(h->p2p_flags, 0, 64 * sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMemset p2p flags");
       h->peers.resize((size_t)V);
     }
   }
