@@ -88,7 +88,9 @@ enum {
   /* replicate_gs (view argument = any owned view for the _ALL phases):
    *   sweep = F_ALL, XTF(own), [all-gather G blocks], G_ALL, XG(own), [all-gather S blocks], S_ALL, [all-gather F blocks] */
   RESNMTF_PHASE_XTF = 5   /* Xt.F pass of owned view v + its k x k job (F'^T F', Ma_G, Md_G) + fold of T into the G block */,
-  RESNMTF_PHASE_G_ALL = 6 /* update_g of EVERY view, in view order (R/update_steps.r:180-207, :295-303) from the G blocks */,
+  RESNMTF_PHASE_G_ALL = 6 /* update_g of EVERY view, in view order (R/update_steps.r:180-207, :295-303) from the G blocks; one launch when
+                             the views have equal column counts and share their columns in the same order (f_chain_kernel's G form at
+                             k <= 16, wide_chain_kernel above), one per view otherwise */,
   RESNMTF_PHASE_XG = 7    /* X.G' pass of owned view v + first half of its k x k job (inputs of the S rule -> S block) +
                              fold of U into the F block */,
   RESNMTF_PHASE_S_ALL = 8 /* update_s, update_lm, error and the F coefficients of EVERY view (s_chain_kernel) */,

@@ -122,6 +122,8 @@ struct resnmtf_handle {
   int n_cu = 256;                     // compute units of the device (multiProcessorCount)
   ChainArgs<8> chain{};               // RESNMTF_PHASE_F_ALL: the F updates of every view in one launch (when eligible)
   int chain_views = 0;                // 0 = not eligible: one launch per view
+  ChainArgs<8> gchain{};              // RESNMTF_PHASE_G_ALL at k <= 16 (replicated G chain): the G updates of every view in one launch
+  int gchain_views = 0, gchain_blocks = 0;
   WideChainArgs<8> wchain[2]{};       // k = 32 / 64: the F ([0]) and G ([1]) updates of every view in one launch (wide_chain_kernel)
   bool wchain_ok[2] = {false, false};
   int wchain_grid[2] = {0, 0};
@@ -333,6 +335,10 @@ hipError_t set_all_attrs() {
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)f_chain_smem_bytes<NVB>()))
   CHAIN_ATTR(2, 1); CHAIN_ATTR(4, 1); CHAIN_ATTR(8, 1); CHAIN_ATTR(2, 4); CHAIN_ATTR(4, 4); CHAIN_ATTR(8, 4);
 #undef CHAIN_ATTR
+#define GCHAIN_ATTR(NVB) TRY_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&f_chain_kernel<NVB, 1, true>), \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)f_chain_smem_bytes<NVB>()))
+  GCHAIN_ATTR(2); GCHAIN_ATTR(4); GCHAIN_ATTR(8);
+#undef GCHAIN_ATTR
 #undef TRY_ATTR
   return hipSuccess;
 }
@@ -466,7 +472,7 @@ ChainArgs<NVB> narrow_chain(const ChainArgs<8>& c) {
   a.len = c.len; a.k = c.k; a.n_views = c.n_views; a.rows_per_block = c.rows_per_block;
   a.n_emit = c.n_emit; a.restricted = c.restricted; a.ctl = c.ctl; a.check_done = c.check_done; a.pstride = c.pstride;
   a.kpack32 = c.kpack32;
-  for (int e = 0; e < 4; ++e) { a.W32e[e] = c.W32e[e]; a.parte[e] = c.parte[e]; }
+  for (int e = 0; e < 4; ++e) { a.W32e[e] = c.W32e[e]; a.parte[e] = c.parte[e]; a.T32e[e] = c.T32e[e]; }
   for (int v = 0; v < NVB; ++v) {
     a.emit_slot[v] = c.emit_slot[v];
     a.W[v] = c.W[v]; a.U[v] = c.U[v]; a.nsplit[v] = c.nsplit[v]; a.Ma[v] = c.Ma[v]; a.Md[v] = c.Md[v]; a.lm[v] = c.lm[v];
@@ -599,6 +605,19 @@ void enqueue_phase_f_all(resnmtf_handle* h, bool checked = false) {
   }
   for (const auto& v : h->views)
     if (v.owned || v.f_replica) launch_update(h, v, 0, checked);
+}
+
+// RESNMTF_PHASE_G_ALL at k <= 16: update_g of every view in one launch (f_chain_kernel, G form) when eligible
+bool enqueue_g_chain(resnmtf_handle* h, bool checked) {
+  if (h->gchain_views <= 0) return false;
+  h->gchain.check_done = checked ? 1 : 0;
+  const int nvw = h->gchain_views;
+  const size_t smem = nvw <= 2 ? f_chain_smem_bytes<2>() : nvw <= 4 ? f_chain_smem_bytes<4>() : f_chain_smem_bytes<8>();
+  const dim3 grid(h->gchain_blocks), block(512);
+  if (nvw <= 2) { ChainArgs<2> a = narrow_chain<2>(h->gchain); LAUNCH_TIMED(h, RESNMTF_TIMED_G_CHAIN, (f_chain_kernel<2, 1, true>), grid, block, smem, a); }
+  else if (nvw <= 4) { ChainArgs<4> a = narrow_chain<4>(h->gchain); LAUNCH_TIMED(h, RESNMTF_TIMED_G_CHAIN, (f_chain_kernel<4, 1, true>), grid, block, smem, a); }
+  else LAUNCH_TIMED(h, RESNMTF_TIMED_G_CHAIN, (f_chain_kernel<8, 1, true>), grid, block, smem, h->gchain);
+  return true;
 }
 
 // ---- the phases of one view (see the header comment)
@@ -2005,6 +2024,50 @@ static void build_chain(resnmtf_handle* h) {
   h->chain_blocks = v0.nblkF;
 }
 
+// RESNMTF_PHASE_G_ALL in one launch at k <= 16 (f_chain_kernel, G form; replicated G chain, R/update_steps.r:195-204): every view
+// holds the inputs of its G update here (owned, or a G replica) as ONE folded slab, hand-off mode A, equal column counts and
+// blocking, every coupling through identity column maps, at most two owned views, at most 8 views.  Else one launch per view.
+static void build_g_chain(resnmtf_handle* h) {
+  h->gchain_views = 0;
+  const int V = h->V;
+  if (V < 2 || V > 8 || h->opt.no_f_chain || !h->opt.replicate_gs || h->sliced) return;
+  const ViewState& v0 = h->views[0];
+  int n_owned = 0;
+  for (int v = 0; v < V; ++v) {
+    const ViewState& vs = h->views[v];
+    if (!vs.owned && !vs.g_replica) return;
+    if (vs.KP != 16 || vs.kk_mode != 0 || vs.half || vs.m != v0.m || vs.k != v0.k || vs.rpbG != v0.rpbG || vs.nblkG != v0.nblkG) return;
+    if (vs.argG.nsplit != 1 || vs.argG.cols_pad != v0.argG.cols_pad) return;
+    if (vs.owned && ++n_owned > 2) return;
+    for (int c = 0; c < vs.argG.n_couple; ++c)
+      if (vs.argG.couple[c].map) return;
+  }
+  ChainArgs<8>& a = h->gchain;
+  a = ChainArgs<8>{};
+  a.len = v0.m; a.k = v0.k; a.n_views = V; a.rows_per_block = v0.rpbG;
+  a.ctl = h->ctl;
+  a.pstride = (size_t)v0.argG.cols_pad * 16;
+  for (int v = 0; v < 8; ++v) a.emit_slot[v] = -1;
+  for (int v = 0; v < V; ++v) {
+    const ViewState& vs = h->views[v];
+    const UpdateArgs& g = vs.argG;
+    if (vs.owned) {
+      a.emit_slot[v] = a.n_emit;
+      a.W32e[a.n_emit] = vs.G32; a.parte[a.n_emit] = vs.partG; a.T32e[a.n_emit] = vs.T32;
+      ++a.n_emit;
+    }
+    a.W[v] = vs.G; a.U[v] = g.P; a.nsplit[v] = 1; a.Ma[v] = vs.Ma_G; a.Md[v] = vs.Md_G; a.lm[v] = vs.mu;
+    a.sigma[v] = g.sigma;
+    a.n_other[v] = (double)vs.m;
+    if (g.restricted) a.restricted |= 1u << v;
+    for (int c = 0; c < g.n_couple; ++c)
+      for (int w = 0; w < V; ++w)
+        if (g.couple[c].W == h->views[w].G) { a.cmask[v] |= 1u << w; a.weight[v][w] = g.couple[c].weight; }
+  }
+  h->gchain_views = V;
+  h->gchain_blocks = v0.nblkG;
+}
+
 // RESNMTF_PHASE_F_ALL / G_ALL in one launch at k = 32 / 64 (wide_chain_kernel): every view holds the inputs of the update
 // here (owned or replica) as ONE folded slab (the exchange blocks of replicate_f / replicate_gs), equal lengths and k,
 // every coupling through identity maps, at most one owned view, at most 8 views.  Otherwise one launch per view.
@@ -2213,6 +2276,7 @@ static int build_args(resnmtf_handle* h) {
     }
   }
   build_chain(h);
+  build_g_chain(h);
   build_wide_chain(h);
   if (h->sliced)
     if (int rc = build_slice_chain(h)) return rc;
@@ -2306,6 +2370,7 @@ int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep) {
     case RESNMTF_PHASE_XTF: launch_pass(h, vs, false, 1, tol, checked); launch_fold_t(h, vs); break;
     case RESNMTF_PHASE_G_ALL:
       if (h->wchain_ok[1]) { launch_wide_chain(h, 1, checked); break; }
+      if (enqueue_g_chain(h, checked)) break;
       for (const auto& w : h->views)
         if (w.owned || w.g_replica) launch_update(h, w, 1, checked);
       break;

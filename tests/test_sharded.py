@@ -274,9 +274,11 @@ def test_wide_chain_f_only_one_process_bitwise(views, k, n, m):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("views,k,n,m", [(3, 24, 700, 200), (6, 32, 333, 161), (4, 64, 1000, 330), (8, 64, 517, 96), (8, 57, 2100, 64), (5, 40, 410, 75)])
+@pytest.mark.parametrize("views,k,n,m", [(3, 24, 700, 200), (6, 32, 333, 161), (4, 64, 1000, 330), (8, 64, 517, 96), (8, 57, 2100, 64), (5, 40, 410, 75),
+                                         (4, 11, 700, 192), (8, 16, 517, 96), (2, 5, 96, 72)])
 def test_wide_chain_one_process_bitwise(views, k, n, m):
-    """One rank's share of a `views`-way sharded run with replicated F / G / S chains at k > 16, in ONE process: view 0
+    """One rank's share of a `views`-way sharded run with replicated F / G / S chains, in ONE process (k > 16: wide_chain_kernel,
+    F and G form; k <= 16: f_chain_kernel, F form and -- round 3 -- its G form with the cross product T^T G' among the partials): view 0
     owned, the others replicas whose exchange blocks are copies of view 0's.  The fused launches (wide_chain_kernel, F and
     G form) against one factor_update_kernel launch per view: every view's F and G bitwise, and the owned view's operand
     copies too (seen through the next pass: the T and U blocks it produces)."""

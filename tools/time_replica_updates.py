@@ -26,6 +26,8 @@ stream = torch.cuda.Stream()
 
 def make(timed):
     opts = dict(slice_chains=True, slice_index=0, slice_count=V) if sliced else {}
+    if os.environ.get("RESNMTF_NO_F_CHAIN") == "1":      # A/B: one launch per view instead of the fused chain launches
+        opts["no_f_chain"] = True
     e = sharded.make_hip_engine(prob, [v == 0 for v in range(V)], 0, stream.cuda_stream, replicate_f=True, replicate_gs=True,
                                 time_kernels=timed, **opts)
     e.reserve_sweeps(sweeps + 8)
