@@ -11,4 +11,6 @@ bash tools/profile_sliced_rank.sh 4 20000 4000 32 --sliced > $O/rank_c4_sliced.l
 bash tools/profile_sliced_rank.sh 4 20000 4000 32 > $O/rank_c4_replicated.log 2>&1
 RESNMTF_BENCH_DEVICE=0 RESNMTF_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 5 --warmup 2 > $O/bench_gpus2_gloo_one_gpu.json 2> $O/bench_gpus2_gloo_one_gpu.err
 RESNMTF_BENCH_DEVICE=0 RESNMTF_BENCH_BACKEND=gloo RESNMTF_BENCH_SHAPE=6000,2000,64 RESNMTF_SLICE_CHAINS=1 python3 bench.py --gpus 4 --steps 5 --warmup 2 > $O/bench_gpus4_sliced_gloo_one_gpu.json 2> $O/bench_gpus4_sliced_gloo_one_gpu.err
+RESNMTF_P2P=1 RESNMTF_BENCH_DEVICE=0 RESNMTF_BENCH_BACKEND=gloo RESNMTF_BENCH_SHAPE=6000,2000,64 RESNMTF_SLICE_CHAINS=1 python3 bench.py --gpus 4 --steps 5 --warmup 2 > $O/bench_gpus4_sliced_p2p_one_gpu.json 2> $O/bench_gpus4_sliced_p2p_one_gpu.err
+python3 tools/time_replica_updates.py 8 10000 2000 16 50 > $O/rank_c2x8_replicated.log 2>&1
 echo done
