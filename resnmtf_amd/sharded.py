@@ -553,6 +553,19 @@ class ShardedSweep:
         if not self.sliced or self._collected:
             return
         import torch
+        if self._tstream is not None:
+            # on the ENGINE's stream: the slices are written by its kernels and the whole factors are read by its finalise /
+            # get_factors, which synchronise that stream only (outside run() torch's current stream is another one: the
+            # slices were once read before the last sweeps had finished)
+            with torch.cuda.stream(self._tstream):
+                self._collect_on_current_stream()
+            self._tstream.synchronize()
+        else:
+            self._collect_on_current_stream()
+        self._collected = True
+
+    def _collect_on_current_stream(self):
+        import torch
         per = dict(zip(("F", "G"), self.engine.slice_info()))
         k = self._k
         for kind in ("F", "G"):
@@ -565,7 +578,6 @@ class ShardedSweep:
             recv = torch.empty_like(send)
             self._all_to_all(recv, send)
             full[self.rank].copy_(recv[:n_el])
-        self._collected = True
 
     def _bcast(self, v: int, which: str):
         t = self.engine.factor_tensor(v, which)
