@@ -503,13 +503,14 @@ def test_replicated_gs_graph_chunk_one_rank_rccl(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,k,n,m", [(2, 16, 700, 200), (3, 40, 301, 97), (4, 64, 1000, 330), (4, 57, 90, 64)])
+@pytest.mark.parametrize("world,k,n,m", [(2, 16, 700, 200), (3, 40, 301, 97), (4, 64, 1000, 330), (4, 57, 90, 64), (4, 32, 20000, 4000)])
 def test_sharded_hip_sliced_chains_peer_stores(tmp_path, world, k, n, m):
     """resnmtf_options.slice_p2p: the four exchanges of a sliced sweep as PEER STORES into the receiving rank's buffers (mapped
     through hipIpc -- here between processes on one GPU; xGMI peer access across GPUs) ordered by arrival counters the consumer's
     stream waits on (hipStreamWaitValue32): no collective in the sweep.  Results against the oracle and BITWISE those of the
-    all-to-all exchange; single receive buffers, ragged and empty slices."""
-    got = launch("gpu_slice_p2p", tmp_path, world=world, k=k, sweeps=14, extra=("--n", n, "--m", m))
+    all-to-all exchange; single receive buffers, ragged and empty slices; the last case is BASELINE's c4 at full size (4 views
+    20000 x 4000, k = 32, phi + psi + xi), four ranks on the one GPU."""
+    got = launch("gpu_slice_p2p", tmp_path, world=world, k=k, sweeps=14, extra=("--n", n, "--m", m), timeout=900)
     assert bool(got["bitwise_vs_replicated"])
     ref = oracle_reference_slice(world, sweeps=14, k=k, n=n, m=m)
     np.testing.assert_allclose(got["all_error"], ref["All_Error"], atol=2e-5, rtol=1e-4)
