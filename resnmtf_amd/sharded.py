@@ -323,7 +323,8 @@ class ShardedSweep:
                          (engine is None or getattr(engine, "supports_sliced", False)))
         n0, m0 = prob.init_f[0].shape[0], prob.init_g[0].shape[0]
         saved_us = 12.0e-6 * self.n_views * (n0 + m0) * k_all[0] * (1.0 - 1.0 / max(self.n_views, 1)) - 30.0
-        self.sliced = bool(can_slice and ((saved_us > 80.0) if want_slice is None else want_slice))
+        # (with the peer-store exchange an extra exchange costs a signal and a stream wait, not a collective launch: slice whenever possible)
+        self.sliced = bool(can_slice and ((saved_us > 80.0 or self.p2p) if want_slice is None else want_slice))
         if want_slice and not self.sliced:
             raise ValueError("slice_chains needs one view per rank (<= 8), equal shapes and k, coupled views sharing all their "
                              "rows / columns in the same order, and coupling that calls for the replicated-chains layout")
