@@ -66,4 +66,11 @@ for name, base in (("F chain", 0), ("G chain", 8)):
     for col, label in ((1, "rows in LDS        "), (2, "pair 0 products    "), (3, "pair 0 walked      "), (4, "end                ")):
         print(f"  {label}", st((t[:, col] - t[:, 0]) / 100.0), " (since entry)")
     print("  end since launch   ", st((t[:, 4] - t0) / 100.0))
+# s_chain_kernel (workgroup w = view w): columns 5 entry, 6 walk done, 7 two k x k products done, 13 error / lambda / mu done, 14 end
+t = tall[:V]
+if (t[:, 5] > 0).any():
+    t0 = t[t[:, 5] > 0][:, 5].min()
+    print(f"== s_chain_kernel ({V} views, k={k}): per workgroup (view): walk done | products done | error done | end   [us since the first entry]")
+    for w in range(V):
+        print(f"  view {w}: entry {(t[w,5]-t0)/100:6.2f}  walk {(t[w,6]-t0)/100:6.2f}  products {(t[w,7]-t0)/100:6.2f}  error {(t[w,13]-t0)/100:6.2f}  end {(t[w,14]-t0)/100:6.2f}")
 eng.close()
