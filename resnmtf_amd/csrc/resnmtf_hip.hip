@@ -905,7 +905,8 @@ WidePlan plan_wide(int ntiles, int rows_pad, int KP, int kinds /* aux products, 
   // kinds) 6 us at k = 32, 18 at k = 64; X.G launch (three kinds, the S rule and the error inside) 14 / 49 us; hand-off mode A
   // (job in workgroup 0 for the whole launch): the earlier, slower figure
   const double r3 = (KP / 64.0) * (KP / 64.0) * (KP / 64.0);
-  const double t_kk = kinds == 3 ? 9.0 + 40.0 * r3 : kinds == 2 ? 4.5 + 13.5 * r3 : 12.0 + 50.0 * r3;
+  // (round 3, k x k products with conflict-free operand reads: 14.8 / 32 us at k = 64, 6 / 13 us at k = 32 -- profiles/r03_stamps_c5_kk.txt)
+  const double t_kk = kinds == 3 ? 9.0 + 23.0 * r3 : kinds == 2 ? 4.5 + 10.3 * r3 : 12.0 + 50.0 * r3;
   WidePlan best;
   double best_aux_time = 1e300;
   int last_na = -1;
