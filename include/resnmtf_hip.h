@@ -363,7 +363,7 @@ int resnmtf_reserve_sweeps(resnmtf_handle* h, int sweeps);
  * X.G pass of every owned view.  Called implicitly by resnmtf_run.  Asynchronous on the stream. */
 int resnmtf_prepare(resnmtf_handle* h);
 /* Enqueue one phase of owned view v (asynchronous).  `sweep` is the 0-based index of the sweep being
- * executed since resnmtf_prepare.  Within a sweep the caller visits the owned views in index order:
+ * executed since resnmtf_prepare (with slice_p2p it also numbers the arrivals a phase waits for: pass the true count).  Within a sweep the caller visits the owned views in index order:
  * PHASE_F, [exchange F], PHASE_G, [exchange G], PHASE_S, [exchange S].  Exchanges enqueued on the
  * handle's stream are ordered against every kernel that reads or writes the exchanged factor. */
 int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep);
