@@ -187,6 +187,11 @@ typedef struct resnmtf_options {
                              resnmtf_prepare.  Receive buffers are single: the order of the sweep itself keeps a writer one
                              exchange behind its reader.  Tested with 2-4 processes on one GPU (IPC on one
                              device); not yet run across GPUs */
+  int xcd_order;          /* 1 (opt-in): the main workgroups of the k > 16 passes renumbered so that every XCD works through a
+                             contiguous range of the split-major list -- a row split's B block is then fetched into one or two
+                             L2s instead of all eight (c5 Xt.F: 154 MB of 1.78 GB per launch).  Measured (tools/round3/xcd_ab.sh):
+                             c4 view +0.7 %, c5 X.G pass +1 %, c5 Xt.F pass -5 % (430 against 409 us) -- the passes are not
+                             bound by those bytes, and concentrating an XCD on one row range costs more than the re-reads: off */
   int fuse_updates;       /* 0 (default): every factor update is a launch of its own.  1 / 2 (opt-in, k <= 16, hand-off mode A, f32
                              images): an UNCOUPLED update_f / update_g (R/update_steps.r:152-155 / :190-193) runs in the first
                              workgroups of the Xt.F / X.G' launch that consumes it, the other workgroups wait for it on an arrival

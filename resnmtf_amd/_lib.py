@@ -41,7 +41,7 @@ class Options(C.Structure):
         ("no_pitch_pad", C.c_int), ("kk_mode", C.c_int), ("bf16_split", C.c_int), ("replicate_f", C.c_int),
         ("no_f_chain", C.c_int), ("x_half", C.c_int), ("half_unroll", C.c_int), ("replicate_gs", C.c_int),
         ("wait_mode", C.c_int), ("slice_chains", C.c_int), ("slice_index", C.c_int), ("slice_count", C.c_int),
-        ("slice_p2p", C.c_int), ("fuse_updates", C.c_int),
+        ("slice_p2p", C.c_int), ("xcd_order", C.c_int), ("fuse_updates", C.c_int),
     ]
 
 

@@ -375,7 +375,24 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
   // operand on the K = 32 MFMA in wide workgroups (f32-grade, default; 1 is accepted as an alias), 2 = plain f32 MFMA
   const int split = v.NT < 2 ? 0 : (h->opt.bf16_split == 2 ? 0 : 3);
   const int main_blocks = split == 3 ? a.ntg * a.nsplit : a.ntiles * a.nsplit;
-  const dim3 grid(a.kk_block0 ? 1 + main_blocks : a.naux * a.nsplit_aux + main_blocks), block(64 * nw);
+  const int lead_blocks = a.kk_block0 ? 1 : a.naux * a.nsplit_aux;       // the k x k job / the aux workgroups head the grid
+  const dim3 grid(lead_blocks + main_blocks), block(64 * nw);
+  a.xcd_n = 0;
+  if (split == 3 && h->opt.xcd_order) {
+    // XCD-aware order of the wide form's main workgroups (PassArgs::xcd_n).  A short last split stays at the end of the grid.
+    const bool short_last = a.nsplit > 1 && a.rows_pad - (a.nsplit - 1) * a.rows_per_split < a.rows_per_split;
+    const int n_map = short_last ? (a.nsplit - 1) * a.ntg : main_blocks;
+    int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int x = 0; x < 8; ++x) a.xcd_first[x] = -1;
+    for (int b = 0; b < n_map; ++b) {
+      const int x = (lead_blocks + b) & 7;
+      if (a.xcd_first[x] < 0) a.xcd_first[x] = lead_blocks + b;
+      ++cnt[x];
+    }
+    int off = 0;
+    for (int x = 0; x < 8; ++x) { a.xcd_off[x] = off; off += cnt[x]; if (a.xcd_first[x] < 0) a.xcd_first[x] = 0; }
+    a.xcd_n = n_map;
+  }
   const size_t smem = std::min<size_t>(pass_smem_bytes(v.KP, nw) + (size_t)h->opt.pass_lds_pad_kb * 1024, kMaxLds);
   // timed mode: the start/stop events are attached to the dispatch itself (hipExtLaunchKernelGGL), so
   // the elapsed time is the kernel's own begin->end, the same quantity rocprofv3 --kernel-trace reports

@@ -42,7 +42,7 @@ class Engine:
                  pass_splits_xtf: int = 0, pass_lds_pad_kb: int = 0, update_blocks: int = 0, no_pitch_pad: bool = False,
                  kk_mode: int = 0, bf16_split: int = 0, replicate_f: bool = False, no_f_chain: bool = False,
                  x_half: int = 0, half_unroll: int = 0, replicate_gs: bool = False, wait_mode: int = 0,
-                 slice_chains: bool = False, slice_index: int = 0, slice_count: int = 0, fuse_updates: int = 0, slice_p2p: bool = False):
+                 slice_chains: bool = False, slice_index: int = 0, slice_count: int = 0, fuse_updates: int = 0, slice_p2p: bool = False, xcd_order: bool = False):
         self._lib = _lib.load()
         self.n_views = len(n_rows)
         self.n_rows = [int(x) for x in n_rows]
@@ -76,6 +76,7 @@ class Engine:
         opts.slice_count = int(slice_count)
         opts.fuse_updates = int(fuse_updates)
         opts.slice_p2p = 1 if slice_p2p else 0
+        opts.xcd_order = 1 if xcd_order else 0
         nr = np.asarray(self.n_rows, dtype=np.int32)
         nc = np.asarray(self.n_cols, dtype=np.int32)
         kk = np.asarray(self.k, dtype=np.int32)

@@ -31,6 +31,8 @@ for name in a.configs:
     gen = time.perf_counter() - t0
     V = len(shapes)
     def mk(**extra):
+        if os.environ.get("RESNMTF_XCD_ORDER") == "1":         # A/B: XCD-aware order of the wide pass's main workgroups (opt-in)
+            extra.setdefault("xcd_order", True)
         e = Engine([s[0] for s in shapes], [s[1] for s in shapes], [k] * V, bf16_split=a.bf16_split, update_blocks=a.update_blocks, **extra)
         for v in range(V):
             e.set_view(v, prob.data[v]); e.set_factors(v, prob.init_f[v], prob.init_s[v], prob.init_g[v])
