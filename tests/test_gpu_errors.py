@@ -79,3 +79,46 @@ def test_torch_imported_after_the_library_still_finds_the_gpu():
     out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "load_order_worker.py")],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "torch after library: ok True" in out.stdout, out.stdout + out.stderr
+
+
+def test_sliced_layout_options_are_checked():
+    """slice_chains / slice_p2p (round 3): layouts that cannot be sliced are refused at create with a message, the peer-store
+    exchange insists on its set-up order, the stop tolerance of the phase API on a replicated S chain."""
+    base = dict(replicate_f=True, replicate_gs=True, slice_chains=True, slice_index=0, slice_count=2)
+    with pytest.raises(ResnmtfError, match="replicate_f and replicate_gs"):
+        Engine([60, 60], [40, 40], [3, 3], owned=[True, False], slice_chains=True, slice_index=0, slice_count=2)
+    with pytest.raises(ResnmtfError, match="equal shapes"):
+        Engine([60, 60], [40, 30], [3, 3], owned=[True, False], **base)
+    with pytest.raises(ResnmtfError, match="exactly one owned view"):
+        Engine([60, 60], [40, 40], [3, 3], owned=[True, True], **base)
+    with pytest.raises(ResnmtfError, match="slice_count"):
+        Engine([60, 60, 60], [40, 40, 40], [3, 3, 3], owned=[True, False, False], **base)
+    with pytest.raises(ResnmtfError, match="slice_p2p needs slice_chains"):
+        Engine([60], [40], [3], slice_p2p=True)
+    prob = synth.make_problem([(60, 40), (60, 40)], 3, phi=1.0, psi=1.0)
+    e = Engine([60, 60], [40, 40], [3, 3], owned=[True, False], slice_p2p=True, **base)
+    assert e.slice_info() == (32, 32)
+    e.set_view(0, prob.data[0])
+    for v in range(2):
+        e.set_factors(v, prob.init_f[v], prob.init_s[v], prob.init_g[v])
+    e.set_restrictions(prob.phi, prob.xi, prob.psi)
+    idx_r, idx_c = np.arange(60, dtype=np.int32), np.arange(40, dtype=np.int32)
+    for v, w in ((0, 1), (1, 0)):
+        e.set_shared_rows(v, w, idx_r, idx_r); e.set_shared_cols(v, w, idx_c, idx_c)
+    e.reserve_sweeps(8)
+    with pytest.raises(ResnmtfError, match="import every rank"):
+        e.prepare()                                        # peers not mapped yet
+    assert len(e.p2p_export()) == 6 * 64
+    e.p2p_import(0)
+    with pytest.raises(ResnmtfError, match="already imported"):
+        e.p2p_import(0)
+    with pytest.raises(ResnmtfError, match="import every rank"):
+        e.prepare()                                        # rank 1 still missing
+    e.close()
+    one = Engine([60], [40], [3])
+    with pytest.raises(ResnmtfError, match="replicated S chain"):
+        one.set_stop_tolerance(1e-6)                       # resnmtf_run has its own stop test
+    one.set_stop_tolerance(-1.0)
+    with pytest.raises(ResnmtfError, match="not a slice_chains handle"):
+        one.slice_info()
+    one.close()
