@@ -192,15 +192,19 @@ def _all_gather_ints(dist, value: int, world: int):
 
 
 def _make_driver(sharded, prob, n_views, rank, world, local_rank, **extra):
-    return sharded.ShardedSweep(prob, owner_of=list(range(n_views)), rank=rank, world=world, device_index=local_rank,
+    if "slice_chains" in extra and extra["slice_chains"] is None:
+        extra.pop("slice_chains")
+    return sharded.ShardedSweep.create(prob, owner_of=list(range(n_views)), rank=rank, world=world, device_index=local_rank,
                                 replicate_f=("force" if os.environ.get("RESNMTF_FORCE_REPLICATE") == "1" else
                                              os.environ.get("RESNMTF_NO_REPLICATE") != "1"),
                                 allgather_blocks=(os.environ.get("RESNMTF_NO_ALLGATHER") != "1"),
                                 **({"replicate_gs": False} if os.environ.get("RESNMTF_NO_REPLICATE_GS") == "1" else {}),
-                                **({"slice_chains": os.environ["RESNMTF_SLICE_CHAINS"] == "1"} if "RESNMTF_SLICE_CHAINS" in os.environ else {}),
+                                **({"slice_chains": os.environ["RESNMTF_SLICE_CHAINS"] == "1"}
+                                   if ("RESNMTF_SLICE_CHAINS" in os.environ and "slice_chains" not in extra) else {}),
                                 **({"overlap_u": False} if os.environ.get("RESNMTF_NO_OVERLAP") == "1" else {}),
-                                # opt-in: the sliced layout's exchanges as peer stores + stream-ordered flags (resnmtf_options.slice_p2p)
-                                **({"slice_p2p": True} if os.environ.get("RESNMTF_P2P") == "1" else {}),
+                                # the exchanges as peer stores + stream-ordered flags (resnmtf_options.slice_p2p): the caller decides
+                                # (run_sharded: after the library's self-test and a bitwise cross-check on this node)
+                                **({"slice_p2p": False} if "slice_p2p" not in extra else {}),
                                 **({"serial_exchange": os.environ["RESNMTF_SERIAL_EXCHANGE"] == "1"}
                                    if "RESNMTF_SERIAL_EXCHANGE" in os.environ else {}), **extra)
 
@@ -245,7 +249,33 @@ def run_sharded(args) -> dict:
     n, m = shapes[rank]
     # every rank builds only the view it owns (same seeds as synth.make_problem) + all initial factors
     prob = sharded.local_problem(n_views, shapes, k, owned=[rank], **coupling)
-    drv = _make_driver(sharded, prob, n_views, rank, world, local_rank)
+    # Exchange form.  RESNMTF_P2P=1 / 0 forces peer stores / collectives; default ("auto"), N > 1: peer stores when (a) the
+    # layout has them, (b) the library's self-test passes on every rank (probe stores, arrivals, stream wait -- host-side
+    # deadlines, nothing can hang) and (c) five sweeps by peer stores give BITWISE the per-view errors of five sweeps of the
+    # same layout with its collectives, here, on this node; otherwise the collectives.  The decision is part of the set-up,
+    # outside the timed region, and is reported in config.
+    want = os.environ.get("RESNMTF_P2P", "auto")
+    use_p2p, p2p_note, force_slice = False, "collectives (RESNMTF_P2P=0)", None
+    if want == "1":
+        use_p2p, p2p_note = True, "peer stores (RESNMTF_P2P=1)"
+    elif want == "auto" and world > 1:
+        probe = _make_driver(sharded, prob, n_views, rank, world, local_rank, slice_p2p="auto")
+        if not probe.p2p:
+            p2p_note = "collectives (no peer-store form for this layout, or the self-test failed: see stderr)"
+            probe.close()
+        else:
+            force_slice = probe.sliced
+            probe.reserve(16); probe.run(5)
+            tab_p = probe.view_error_table()
+            probe.close()
+            ref = _make_driver(sharded, prob, n_views, rank, world, local_rank, slice_p2p=False, slice_chains=force_slice)
+            ref.reserve(16); ref.run(5)
+            tab_c = ref.view_error_table()
+            ref.close()
+            use_p2p = bool(np.array_equal(tab_p, tab_c) and np.isfinite(tab_p).all())
+            p2p_note = ("peer stores (self-test passed; 5 sweeps bitwise equal to the collective exchange on this node)" if use_p2p else
+                        "collectives (peer stores disagreed with the collective exchange on this node)")
+    drv = _make_driver(sharded, prob, n_views, rank, world, local_rank, slice_p2p=use_p2p, slice_chains=force_slice)
     if os.environ.get("RESNMTF_FORCE_BCAST") == "1":      # rehearsal: issue the F broadcast even with one rank
         drv.plan[0]["F"] = True
     drv.reserve(args.warmup + args.steps + 8)      # per-sweep error slots for both run() calls
@@ -268,6 +298,7 @@ def run_sharded(args) -> dict:
     replicated_gs = drv.replicate_gs
     sliced = drv.sliced
     per_sweep = drv.collectives_per_sweep
+    p2p = drv.p2p
     overlapped = getattr(drv, "_group_u", None) is not None
     n_devices = len({int(d) for d in _all_gather_ints(dist, local_rank, world)})
     drv.close()
@@ -277,7 +308,7 @@ def run_sharded(args) -> dict:
     kt = None
     t_steps = max(2, min(args.steps, 30))
     try:
-        drv_t = _make_driver(sharded, prob, n_views, rank, world, local_rank, time_kernels=True)
+        drv_t = _make_driver(sharded, prob, n_views, rank, world, local_rank, time_kernels=True, slice_p2p=use_p2p, slice_chains=force_slice)
         drv_t.reserve(t_steps + 8)
         drv_t.run(2)
         torch.cuda.synchronize()
@@ -339,6 +370,10 @@ def run_sharded(args) -> dict:
     layout = (("F and G chains ROW-SLICED over the ranks, S chain replicated; exchange by peer stores into the receivers' buffers (hipIpc / xGMI) "
                "ordered by stream-waited arrival counters, no collective in the sweep")
               if (sliced and per_sweep == 0) else
+              (("F, G and S chains replicated on every rank" if replicated_gs else "F chain replicated on every rank") +
+               "; the exchange blocks stored straight into every peer's arena (hipIpc / xGMI), ordered by stream-waited arrival counters, "
+               "no collective in the sweep")
+              if (per_sweep == 0 and p2p) else
               ("F and G chains ROW-SLICED over the ranks (all-to-all of row slices), S chain replicated; "
                f"{per_sweep} collectives per sweep between dependent steps" + (", U slices on a second communicator beside the S chain" if overlapped else ""))
               if sliced else
@@ -355,6 +390,7 @@ def run_sharded(args) -> dict:
                                + " (all rows / columns of coupled views shared), one view per GPU, Gauss-Seidel order kept exactly; " + layout,
                    "n_views": n_views, "shapes": [list(sh) for sh in shapes], "k": k,
                    "backend": ("rccl" if backend == "nccl" else backend), "world_size": world, "distinct_devices": n_devices,
+                   "exchange": p2p_note,
                    "final_error": float(errs[-1]) if len(errs) else None,
                    "scaling_note": "BASELINE.json prescribes a different workload per GPU count (c3 / c4 / c5): compare value / n_gpus "
                                    "with the one-view rate of the same shape (roofline.single_view_updates_per_s), not across N"},
@@ -378,7 +414,13 @@ def spawn_ranks(args) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out, _ = procs[0].communicate()
+    try:
+        out, _ = procs[0].communicate(timeout=float(os.environ.get("RESNMTF_BENCH_DEADLINE_S", "1500")))
+    except subprocess.TimeoutExpired:      # a rank that never comes back must not hold the caller for ever
+        print("[bench] rank 0 did not finish in time: stopping the ranks this process started", file=sys.stderr)
+        for p in procs:
+            p.kill()
+        out, _ = procs[0].communicate()
     rc = procs[0].returncode
     for p in procs[1:]:
         try:

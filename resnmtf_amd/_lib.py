@@ -95,6 +95,7 @@ SIGNATURES = {
     "resnmtf_slice_info": (C.c_int, [_h, _ip, _ip]),
     "resnmtf_p2p_export": (C.c_int, [_h, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "resnmtf_p2p_import": (C.c_int, [_h, C.c_int, C.c_void_p, C.c_size_t]),
+    "resnmtf_p2p_selftest": (C.c_int, [_h, C.c_int]),
 }
 
 _lib = None

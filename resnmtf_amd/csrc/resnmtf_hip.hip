@@ -23,6 +23,7 @@
 #include <cstring>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "resnmtf_hip.h"
@@ -149,10 +150,13 @@ struct resnmtf_handle {
   // mapped through hipIpc (own rank: the local pointers); flags[e] counts the arrivals of exchange e (0 U + S blocks, 1 new F
   // rows, 2 T slices, 3 new G rows): V per sweep
   struct Peer { char *u_recv = nullptr, *t_recv = nullptr; float *f_recv = nullptr, *g_recv = nullptr; double* sblk = nullptr;
+                char *fblk_arena = nullptr, *gblk_arena = nullptr;      // block_p2p: the replicated layouts' exchange arenas
                 unsigned int* flags = nullptr; bool imported = false; void* opened[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; };
   std::vector<Peer> peers;
   unsigned int* p2p_flags = nullptr;
   bool p2p_ready = false, p2p_prepared = false;
+  unsigned int probe_epoch = 0;       // resnmtf_p2p_selftest calls so far (its arrival counter is cumulative)
+  bool block_p2p = false;             // slice_p2p without slice_chains: the exchange blocks of the replicated layouts by peer stores
   WideChainArgs<8> schain[2]{};       // SLICE_F ([0]) / SLICE_G ([1])
   int schain_grid[2] = {0, 0};
   double ktime_ms[RESNMTF_TIMED_KINDS] = {0, 0, 0, 0, 0, 0};     // time_kernels: per kind (resnmtf_kernel_timings)
@@ -684,6 +688,42 @@ void p2p_signal(resnmtf_handle* h, int e) {
 hipError_t p2p_wait(resnmtf_handle* h, int e, unsigned int arrivals) {
   return hipStreamWaitValue32(h->stream, h->p2p_flags + e, arrivals, hipStreamWaitValueGte, 0xFFFFFFFFu);
 }
+// block_p2p: byte ranges [off0, off0 + b0) and [off1, off1 + b1) of this rank's part of an arena -> the same place on every peer
+// kind 0: F exchange arena, 1: G exchange arena, 2: S block arena
+void launch_block_push(resnmtf_handle* h, int kind, size_t off0, size_t b0, size_t off1, size_t b1) {
+  BlockPushArgs a{};
+  a.src = static_cast<const char*>(kind == 0 ? h->fblk_arena : kind == 1 ? h->gblk_arena : (void*)h->sblk_arena);
+  for (int c = 0; c < h->V; ++c) {
+    if (c == h->opt.slice_index) continue;
+    const resnmtf_handle::Peer& pc = h->peers[(size_t)c];
+    a.dst[a.n_dst++] = kind == 0 ? pc.fblk_arena : kind == 1 ? pc.gblk_arena : reinterpret_cast<char*>(pc.sblk);
+  }
+  if (a.n_dst == 0) return;
+  a.off[0] = off0; a.bytes[0] = b0; a.off[1] = off1; a.bytes[1] = b1;
+  const size_t quads = (b0 + b1) / 16;
+  LAUNCH_TIMED(h, RESNMTF_TIMED_PACK, block_push_kernel, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((quads + 255) / 256, 2048))), dim3(256), 0, a);
+}
+// the F exchange block of an owned view to the peers: everything (replicate_f alone: the owner's coefficients and lambda are
+// the only copy) or, with the replicated S chain, the U rows and the embedded S block only -- every rank computes the
+// coefficients, lambda and mu of every view itself and a late store must not land on them
+void push_f_block(resnmtf_handle* h, const ViewState& v) {
+  const size_t base = (size_t)(static_cast<const char*>(v.fblk) - static_cast<const char*>(h->fblk_arena));
+  if (!h->opt.replicate_gs) { launch_block_push(h, 0, base, v.fblk_bytes, 0, 0); return; }
+  const size_t usum = ((size_t)v.n_pad * v.KP * sizeof(float) + 255) / 256 * 256;
+  if (h->sblk_embedded) {
+    const size_t s_off = (size_t)(reinterpret_cast<const char*>(v.sblk) - static_cast<const char*>(h->fblk_arena));
+    launch_block_push(h, 0, base, usum, s_off, h->sblk_stride * sizeof(double));
+  } else {
+    launch_block_push(h, 0, base, usum, 0, 0);
+    const size_t sb = (h->sblk_stride * sizeof(double));
+    launch_block_push(h, 2, (size_t)(&v - h->views.data()) * sb, sb / 16 * 16, 0, 0);
+  }
+}
+void push_g_block(resnmtf_handle* h, const ViewState& v) {      // [Tsum | Ma_G | Md_G], not mu
+  const size_t base = (size_t)(static_cast<const char*>(v.gblk) - static_cast<const char*>(h->gblk_arena));
+  const size_t tsum = ((size_t)v.m_pad * v.KP * sizeof(float) + 255) / 256 * 256;
+  launch_block_push(h, 1, base, (tsum + 2 * (size_t)v.k * v.k * sizeof(double)) / 16 * 16, 0, 0);
+}
 // slice_chains: the own view's new F (g == 0) / G (g == 1) rows, as received, -> the operand copies of the next pass
 void launch_slice_unpack(resnmtf_handle* h, const ViewState& v, int g, bool checked) {
   SliceUnpackArgs a{};
@@ -1079,7 +1119,17 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
       }
     if (why) { g_create_error = why; return RESNMTF_ERR_INVALID; }
   }
-  if (o.slice_p2p && !o.slice_chains) { g_create_error = "slice_p2p needs slice_chains"; return RESNMTF_ERR_INVALID; }
+  if (o.slice_p2p && !o.slice_chains) {      // peer stores for the exchange blocks of the replicated layouts
+    const char* why = nullptr;
+    if (!o.replicate_f) why = "slice_p2p needs slice_chains or the replicated chains (replicate_f)";
+    else if (o.slice_count != n_views || n_views < 1 || n_views > 8) why = "slice_p2p needs slice_count = number of views <= 8";
+    else if (o.slice_index < 0 || o.slice_index >= o.slice_count) why = "slice_index out of range";
+    else if (!owned) why = "slice_p2p needs exactly one owned view (view index = slice_index)";
+    else
+      for (int v = 0; v < n_views && !why; ++v)
+        if ((owned[v] != 0) != (v == o.slice_index)) why = "slice_p2p needs exactly one owned view (view index = slice_index)";
+    if (why) { g_create_error = why; return RESNMTF_ERR_INVALID; }
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
     g_create_error = "no HIP device available (this library has no CPU fallback)";
@@ -1198,20 +1248,21 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     if ((e = dev_alloc_zero(&h->f_recv, (size_t)V * h->sl_rows * v0.KP)) != hipSuccess) return bail(e, "hipMalloc slice exchange buffers");
     if ((e = dev_alloc_zero(&h->g_send, (size_t)V * h->sl_cols * v0.KP)) != hipSuccess) return bail(e, "hipMalloc slice exchange buffers");
     if ((e = dev_alloc_zero(&h->g_recv, (size_t)V * h->sl_cols * v0.KP)) != hipSuccess) return bail(e, "hipMalloc slice exchange buffers");
-    if (o.slice_p2p) {
-      int can = 0;
-      (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, o.device_id);
-      if (!can) { g_create_error = "slice_p2p needs hipStreamWaitValue32 (hipDeviceAttributeCanUseStreamWaitValue)"; resnmtf_destroy(h); return RESNMTF_ERR_NO_DEVICE; }
-      // the arrival counters are written by other devices' atomics and polled by this device's command processor: fine-grained
-      // (coherent) memory where the runtime offers it
-      if (hipExtMallocWithFlags(reinterpret_cast<void**>(&h->p2p_flags), 64 * sizeof(unsigned int), hipDeviceMallocFinegrained) != hipSuccess) {
-        (void)hipGetLastError();
-        h->p2p_flags = nullptr;
-        if ((e = hipMalloc(reinterpret_cast<void**>(&h->p2p_flags), 64 * sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMalloc p2p flags");
-      }
-      if ((e = hipMemset(h->p2p_flags, 0, 64 * sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMemset p2p flags");
-      h->peers.resize((size_t)V);
+  }
+  if (o.slice_p2p) {
+    int can = 0;
+    (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, o.device_id);
+    if (!can) { g_create_error = "slice_p2p needs hipStreamWaitValue32 (hipDeviceAttributeCanUseStreamWaitValue)"; resnmtf_destroy(h); return RESNMTF_ERR_NO_DEVICE; }
+    // the arrival counters are written by other devices' atomics and polled by this device's command processor: fine-grained
+    // (coherent) memory where the runtime offers it
+    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&h->p2p_flags), 64 * sizeof(unsigned int), hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      h->p2p_flags = nullptr;
+      if ((e = hipMalloc(reinterpret_cast<void**>(&h->p2p_flags), 64 * sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMalloc p2p flags");
     }
+    if ((e = hipMemset(h->p2p_flags, 0, 64 * sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMemset p2p flags");
+    h->peers.resize((size_t)n_views);
+    h->block_p2p = !o.slice_chains;
   }
   size_t fblk_off = 0, gblk_off = 0;
   for (int v = 0; v < n_views; ++v) {
@@ -2365,6 +2416,8 @@ int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep) {
     return h->fail(RESNMTF_ERR_STATE, "slice_chains: use PHASE_SLICE_F / SLICE_XTF / SLICE_G / SLICE_XG / S_ALL");
   if ((phase == RESNMTF_PHASE_SLICE_XTF || phase == RESNMTF_PHASE_SLICE_XG) && !vs.owned)
     return h->fail(RESNMTF_ERR_STATE, "phase on a view this handle does not own");
+  if (h->block_p2p && !h->opt.replicate_gs && phase != RESNMTF_PHASE_LOCAL_SWEEP)
+    return h->fail(RESNMTF_ERR_STATE, "slice_p2p with replicate_f alone: the sweep is RESNMTF_PHASE_LOCAL_SWEEP (one exchange per sweep)");
   if (h->opt.replicate_gs && (phase == RESNMTF_PHASE_G || phase == RESNMTF_PHASE_LOCAL_SWEEP))
     return h->fail(RESNMTF_ERR_STATE, "replicate_gs: use PHASE_XTF / G_ALL / XG / S_ALL instead of PHASE_G");
   if (sweep < 0) return h->fail(RESNMTF_ERR_INVALID, "negative sweep index");
@@ -2383,21 +2436,47 @@ int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep) {
     case RESNMTF_PHASE_S: break;   // S is complete behind PHASE_G on the handle's stream
     case RESNMTF_PHASE_F_ALL: enqueue_phase_f_all(h, checked); break;
     case RESNMTF_PHASE_LOCAL_SWEEP:
+      if (h->block_p2p) {
+        // peer-store form of the one-exchange layout: the F chain waits for the V blocks stored after sweep t - 1 (the first
+        // ones travel by the caller's collective after resnmtf_prepare), says so to every rank once it has read them, and the
+        // own block of this sweep is stored only after every rank has said so (the ack has long arrived: two passes lie between)
+        if (sweep > 0) HIP_TRY(h, p2p_wait(h, 0, (unsigned)h->V * (unsigned)sweep));
+        enqueue_phase_f_all(h);
+        p2p_signal(h, 1);
+        for (const auto& w : h->views)
+          if (w.owned) enqueue_phase_g(h, w, -1.0, false);
+        HIP_TRY(h, p2p_wait(h, 1, (unsigned)h->V * (unsigned)(sweep + 1)));
+        for (const auto& w : h->views)
+          if (w.owned) push_f_block(h, w);
+        p2p_signal(h, 0);
+        break;
+      }
       if (int rc = launch_local_sweep(h)) return rc;
       break;
-    case RESNMTF_PHASE_XTF: launch_pass(h, vs, false, 1, tol, checked); launch_fold_t(h, vs); break;
+    // block_p2p with the replicated G / S chains: the own T block is stored to the peers behind the Xt.F pass, the own U rows
+    // and S block behind the X.G pass; G_ALL / S_ALL wait for the V arrivals of their sweep.  Single arenas: the sweep's own
+    // order keeps a writer behind its readers, and what every rank computes itself (coefficients,
+    // lambda, mu) is never stored to a peer
+    case RESNMTF_PHASE_XTF:
+      launch_pass(h, vs, false, 1, tol, checked); launch_fold_t(h, vs);
+      if (h->block_p2p) { push_g_block(h, vs); p2p_signal(h, 1); }
+      break;
     case RESNMTF_PHASE_G_ALL:
+      if (h->block_p2p) HIP_TRY(h, p2p_wait(h, 1, (unsigned)h->V * (unsigned)(sweep + 1)));
       if (h->wchain_ok[1]) { launch_wide_chain(h, 1, checked); break; }
       if (enqueue_g_chain(h, checked)) break;
       for (const auto& w : h->views)
         if (w.owned || w.g_replica) launch_update(h, w, 1, checked);
       break;
-    case RESNMTF_PHASE_XG: launch_pass(h, vs, true, 1, tol, checked); launch_fold(h, vs); break;
+    case RESNMTF_PHASE_XG:
+      launch_pass(h, vs, true, 1, tol, checked); launch_fold(h, vs);
+      if (h->block_p2p) { push_f_block(h, vs); p2p_signal(h, 0); }
+      break;
     // slice_p2p: every phase first waits (in stream order, hipStreamWaitValue32) until the V arrivals of the exchange that
     // feeds it are in, and ends with one arrival on every rank's counter of the exchange it fed with peer stores.
     // Arrivals so far: U + S blocks V (t + 2) after sweep t's X.G (the run prologue is the first), the others V (t + 1).
     case RESNMTF_PHASE_S_ALL:
-      if (h->opt.slice_p2p) HIP_TRY(h, p2p_wait(h, 0, (unsigned)h->V * (unsigned)(sweep + 2)));
+      if (h->opt.slice_p2p) HIP_TRY(h, p2p_wait(h, 0, (unsigned)h->V * (unsigned)(sweep + (h->block_p2p ? 1 : 2))));
       if (int rc = launch_s_chain(h, checked)) return rc;
       break;
     case RESNMTF_PHASE_SLICE_F:
@@ -2707,15 +2786,29 @@ int resnmtf_slice_info(resnmtf_handle* h, int* rows_per_slice, int* cols_per_sli
   return RESNMTF_OK;
 }
 
+// what a rank maps of every other rank: sliced chains -- the four receive buffers and the S block arena; block form -- the
+// exchange arenas of the replicated layouts (those the layout has); the arrival counters in both
+static void p2p_buffers(resnmtf_handle* h, void* bufs[6]) {
+  if (h->block_p2p) {
+    bufs[0] = h->fblk_arena; bufs[1] = nullptr; bufs[2] = h->gblk_arena; bufs[3] = nullptr; bufs[4] = h->sblk_arena;
+  } else {
+    bufs[0] = h->u_recv; bufs[1] = h->f_recv; bufs[2] = h->t_recv; bufs[3] = h->g_recv; bufs[4] = h->sblk_arena;
+  }
+  bufs[5] = h->p2p_flags;
+}
+
 int resnmtf_p2p_export(resnmtf_handle* h, void* handles, size_t capacity, size_t* bytes) {
   if (!h || !bytes) return RESNMTF_ERR_INVALID;
   if (!h->opt.slice_p2p) return h->fail(RESNMTF_ERR_STATE, "not a slice_p2p handle");
   *bytes = 6 * sizeof(hipIpcMemHandle_t);
   if (!handles || capacity < *bytes) return h->fail(RESNMTF_ERR_INVALID, "handle buffer too small");
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
-  void* bufs[6] = {h->u_recv, h->f_recv, h->t_recv, h->g_recv, h->sblk_arena, h->p2p_flags};
+  void* bufs[6];
+  p2p_buffers(h, bufs);
   auto* out = static_cast<hipIpcMemHandle_t*>(handles);
-  for (int b = 0; b < 6; ++b) HIP_TRY(h, hipIpcGetMemHandle(&out[b], bufs[b]));
+  std::memset(out, 0, *bytes);
+  for (int b = 0; b < 6; ++b)
+    if (bufs[b]) HIP_TRY(h, hipIpcGetMemHandle(&out[b], bufs[b]));
   return RESNMTF_OK;
 }
 
@@ -2727,23 +2820,96 @@ int resnmtf_p2p_import(resnmtf_handle* h, int rank, const void* handles, size_t 
   if (pc.imported) return h->fail(RESNMTF_ERR_STATE, "rank already imported");
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
   void* ptr[6];
+  void* own[6];
+  p2p_buffers(h, own);
   if (rank == h->opt.slice_index) {
-    void* own[6] = {h->u_recv, h->f_recv, h->t_recv, h->g_recv, h->sblk_arena, h->p2p_flags};
     for (int b = 0; b < 6; ++b) ptr[b] = own[b];
   } else {
     if (!handles || bytes < 6 * sizeof(hipIpcMemHandle_t)) return h->fail(RESNMTF_ERR_INVALID, "handle buffer too small");
     const auto* in = static_cast<const hipIpcMemHandle_t*>(handles);
     for (int b = 0; b < 6; ++b) {
+      ptr[b] = nullptr;
+      if (!own[b]) continue;              // (every rank has the same layout: a buffer this rank lacks, the peer lacks too)
       HIP_TRY(h, hipIpcOpenMemHandle(&ptr[b], in[b], hipIpcMemLazyEnablePeerAccess));
       pc.opened[b] = ptr[b];
     }
   }
-  pc.u_recv = static_cast<char*>(ptr[0]); pc.f_recv = static_cast<float*>(ptr[1]); pc.t_recv = static_cast<char*>(ptr[2]);
-  pc.g_recv = static_cast<float*>(ptr[3]); pc.sblk = static_cast<double*>(ptr[4]); pc.flags = static_cast<unsigned int*>(ptr[5]);
+  if (h->block_p2p) {
+    pc.fblk_arena = static_cast<char*>(ptr[0]); pc.gblk_arena = static_cast<char*>(ptr[2]);
+  } else {
+    pc.u_recv = static_cast<char*>(ptr[0]); pc.f_recv = static_cast<float*>(ptr[1]); pc.t_recv = static_cast<char*>(ptr[2]);
+    pc.g_recv = static_cast<float*>(ptr[3]);
+  }
+  pc.sblk = static_cast<double*>(ptr[4]); pc.flags = static_cast<unsigned int*>(ptr[5]);
   pc.imported = true;
   h->p2p_ready = true;
   for (const auto& q : h->peers) h->p2p_ready = h->p2p_ready && q.imported;
   h->prepared = false;
+  return RESNMTF_OK;
+}
+
+// Every rank calls this at about the same time, after all imports and a host barrier, before resnmtf_prepare.  Host-side
+// deadlines everywhere: a node on which peer stores, remote atomics or the stream wait do not work is reported, not hung on.
+int resnmtf_p2p_selftest(resnmtf_handle* h, int timeout_ms) {
+  if (!h) return RESNMTF_ERR_INVALID;
+  if (!h->opt.slice_p2p) return h->fail(RESNMTF_ERR_STATE, "not a slice_p2p handle");
+  if (!h->p2p_ready) return h->fail(RESNMTF_ERR_STATE, "slice_p2p: import every rank's buffers first (resnmtf_p2p_import)");
+  if (h->p2p_prepared) return h->fail(RESNMTF_ERR_STATE, "resnmtf_p2p_selftest precedes resnmtf_prepare (it writes into the receive buffers)");
+  HIP_TRY(h, hipSetDevice(h->opt.device_id));
+  const int V = h->V, r = h->opt.slice_index, kProbeFlag = 8, kWords = 256;
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms > 0 ? timeout_ms : 10000);
+  // where rank `from` writes on rank `on` (a place the run prologue overwrites): block form -- the head of view `from`'s U
+  // rows in the F arena; sliced form -- the head of chunk `from` of the U receive buffer
+  auto region = [&](char* f_arena, char* u_recv, int from) -> unsigned int* {
+    if (h->block_p2p) return reinterpret_cast<unsigned int*>(f_arena + (static_cast<const char*>(h->views[(size_t)from].fblk) - static_cast<const char*>(h->fblk_arena)));
+    return reinterpret_cast<unsigned int*>(u_recv + (size_t)from * h->u_chunk);
+  };
+  P2pProbeArgs a{};
+  a.tag = 0xA5000000u | ((unsigned)r << 16) | ((h->probe_epoch & 0xFFu) << 8);
+  for (int c = 0; c < V; ++c)
+    if (c != r) a.dst[a.n_dst++] = region(h->peers[(size_t)c].fblk_arena, h->peers[(size_t)c].u_recv, r);
+  if (a.n_dst) hipLaunchKernelGGL(p2p_probe_kernel, dim3(1), dim3(kWords), 0, h->stream, a);
+  p2p_signal(h, kProbeFlag);
+  HIP_TRY(h, hipGetLastError());
+  const unsigned int want = (unsigned)V * (h->probe_epoch + 1);
+  h->probe_epoch += 1;
+  // 1. the V arrivals (remote system-scope atomics on this rank's counter), polled from the host
+  unsigned int seen = 0;
+  for (;;) {
+    HIP_TRY(h, hipMemcpy(&seen, h->p2p_flags + kProbeFlag, sizeof(seen), hipMemcpyDeviceToHost));
+    if (seen >= want) break;
+    if (std::chrono::steady_clock::now() > deadline) {
+      char msg[160];
+      std::snprintf(msg, sizeof(msg), "slice_p2p self-test: %u of %u arrivals within the deadline (peer atomics do not reach this rank)", seen, want);
+      return h->fail(RESNMTF_ERR_HIP, msg);
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  }
+  // 2. what the peers stored before they signalled is here
+  std::vector<unsigned int> got((size_t)kWords);
+  for (int c = 0; c < V; ++c) {
+    if (c == r) continue;
+    unsigned int* mine = region(static_cast<char*>(h->fblk_arena), h->u_recv, c);
+    HIP_TRY(h, hipMemcpy(got.data(), mine, kWords * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    const unsigned int tag = 0xA5000000u | ((unsigned)c << 16) | (((h->probe_epoch - 1) & 0xFFu) << 8);
+    for (int i = 0; i < kWords; ++i)
+      if (got[(size_t)i] != (tag | (unsigned)i)) {
+        char msg[160];
+        std::snprintf(msg, sizeof(msg), "slice_p2p self-test: word %d from rank %d reads %08x after its arrival (peer stores not visible)", i, c, got[(size_t)i]);
+        return h->fail(RESNMTF_ERR_HIP, msg);
+      }
+    HIP_TRY(h, hipMemset(mine, 0, kWords * sizeof(unsigned int)));
+  }
+  // 3. the stream wait the phases use sees the counter
+  HIP_TRY(h, p2p_wait(h, kProbeFlag, want));
+  for (;;) {
+    const hipError_t q = hipStreamQuery(h->stream);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) return h->fail_hip("hipStreamQuery", q);
+    if (std::chrono::steady_clock::now() > deadline)
+      return h->fail(RESNMTF_ERR_HIP, "slice_p2p self-test: hipStreamWaitValue32 does not see the arrival counter (the handle's stream is blocked: destroy the handle)");
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  }
   return RESNMTF_OK;
 }
 

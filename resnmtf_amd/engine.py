@@ -287,6 +287,11 @@ class Engine:
         buf = C.create_string_buffer(handles, max(len(handles), 1))
         self._check(self._lib.resnmtf_p2p_import(self._h, int(rank), buf, len(handles)))
 
+    def p2p_selftest(self, timeout_ms: int = 10000):
+        """slice_p2p: probe stores, arrivals and the stream wait with host-side deadlines (every rank, after the imports and a
+        barrier, before prepare); raises ResnmtfError when the node cannot run the peer-store exchange."""
+        self._check(self._lib.resnmtf_p2p_selftest(self._h, int(timeout_ms)))
+
     def kernel_timings(self, reset: bool = False) -> dict:
         """time_kernels: {kind: (ms_total, launches)} for the kernels of a view-sharded sweep."""
         n = len(_lib.TIMED_KINDS)

@@ -165,6 +165,9 @@ class HipEngineAdapter:
     def p2p_import(self, rank, handles=b""):
         self.e.p2p_import(rank, handles)
 
+    def p2p_selftest(self, timeout_ms=10000):
+        self.e.p2p_selftest(timeout_ms)
+
     def __init__(self, engine):
         self.e = engine
         self._views: Dict[tuple, object] = {}
@@ -275,8 +278,28 @@ def local_problem(n_views: int, shape, k: int, phi: float = 0.0, xi: float = 0.0
     return prob
 
 
+class P2PUnavailable(RuntimeError):
+    """The peer-store exchange cannot be used (layout or node); raised on every rank alike."""
+
+
 class ShardedSweep:
     """Runs sweeps of a problem whose views are spread over the ranks of a process group."""
+
+    @classmethod
+    def create(cls, prob, owner_of, rank, world, slice_p2p="auto", **kw):
+        """``slice_p2p="auto"``: the peer-store exchange when the layout has one and the node passes the library's self-test
+        (resnmtf_p2p_selftest: probe stores, arrivals and the stream wait under host-side deadlines, the same outcome on every
+        rank), else the same layout with its collectives.  True / False: as the constructor."""
+        if slice_p2p != "auto":
+            return cls(prob, owner_of, rank, world, slice_p2p=bool(slice_p2p), **kw)
+        if world > 1 and kw.get("engine") is None and kw.get("engine_factory") is None:
+            try:
+                return cls(prob, owner_of, rank, world, slice_p2p=True, **kw)
+            except (P2PUnavailable, ValueError) as exc:      # (both deterministic across ranks)
+                if rank == 0:
+                    import sys
+                    print(f"[resnmtf_amd.sharded] peer-store exchange not used: {exc}", file=sys.stderr)
+        return cls(prob, owner_of, rank, world, slice_p2p=False, **kw)
 
     def __init__(self, prob: Problem, owner_of: Sequence[int], rank: int, world: int,
                  device_index: int = 0, group=None, engine=None,
@@ -353,7 +376,10 @@ class ShardedSweep:
             self._tstream = torch.cuda.Stream(device=device_index)
             self._xstream = self._tstream if self._serial else torch.cuda.Stream(device=device_index)
             if self.p2p and not self.sliced:
-                raise ValueError("slice_p2p is an exchange form of the sliced-chains layout")
+                # block form: the exchange blocks of the replicated layouts by peer stores (one view per rank, every view replicated)
+                if not (all(self.replicated) and self.owner_of == list(range(world)) and self.n_views == world and world <= 8):
+                    raise ValueError("slice_p2p needs the sliced or the replicated-chains layout with one view per rank (<= 8)")
+                engine_opts = dict(engine_opts, slice_index=rank, slice_count=world, slice_p2p=True)
             if self.sliced:
                 engine_opts = dict(engine_opts, slice_chains=True, slice_index=rank, slice_count=world, slice_p2p=self.p2p)
             self.engine = make_hip_engine(prob, self.owned, device_index, self._tstream.cuda_stream,
@@ -374,7 +400,7 @@ class ShardedSweep:
         self._ustream = None
         self._ev_u = self._ev_xg = None
         self._collected = True
-        if self.sliced and self.p2p:
+        if self.p2p:
             # peer stores + stream-ordered flags instead of collectives (resnmtf_options.slice_p2p): every rank maps every
             # rank's receive buffers (hipIpc; the handles travel as objects over the process group, once), then a barrier --
             # nobody signals before everybody has mapped and zeroed
@@ -386,6 +412,23 @@ class ShardedSweep:
             for r in range(world):
                 self.engine.p2p_import(r, b"" if r == rank else everyone[r])
             dist.barrier(group=group)
+            # probe stores / arrivals / the stream wait under host-side deadlines; every rank learns every rank's outcome
+            problem = None
+            if not self.sliced and not self.replicate_gs and not (self._allgather_blocks and not any(p["G"] or p["S"] for p in self.plan)):
+                problem = ("slice_p2p with the replicated F chain alone needs the one-exchange layout (equal F blocks, "
+                           "no G / S coupling across ranks)")
+            else:
+                try:
+                    self.engine.p2p_selftest(10000)
+                except Exception as exc:      # (ResnmtfError: reported, never hung on)
+                    problem = f"rank {rank}: {exc}"
+            outcomes: List[Optional[str]] = [None] * world
+            dist.all_gather_object(outcomes, problem, group=group)
+            failed = [o for o in outcomes if o]
+            if failed:
+                dist.barrier(group=group)      # nobody unmaps while a peer may still be probing
+                self.engine.close()
+                raise P2PUnavailable("; ".join(failed))
         elif self.sliced and self._tstream is not None and self._overlap_u and dist.get_backend(group) == "nccl":
             import torch
             self._group_u = dist.new_group(ranks=list(range(world)), backend="nccl")      # collective: every rank gets here
@@ -397,6 +440,9 @@ class ShardedSweep:
         # with), so it is issued on the compute stream itself -- measured with one rank on RCCL: 54.6 us per
         # sweep against 90.0 us through a second stream and its event edges
         if self._allgather_blocks and serial_opt is None and self._tstream is not None:
+            self._serial = True
+            self._xstream = self._tstream
+        if self.p2p and self._tstream is not None:       # the stream waits of the phases order everything: one stream
             self._serial = True
             self._xstream = self._tstream
 
@@ -420,7 +466,7 @@ class ShardedSweep:
     @property
     def collectives_per_sweep(self) -> int:
         """Collectives between dependent steps of one sweep in the replicated-chains layouts (0: ordered broadcasts)."""
-        if self.sliced and self.p2p:
+        if self.p2p:
             return 0             # peer stores + stream-ordered flags
         if self.sliced:          # F rows back, T slices, G rows back, S blocks (+ the U slices beside the S chain when overlapped)
             return 4 if self._group_u is not None else 5
@@ -478,6 +524,10 @@ class ShardedSweep:
             lambda, mu, error, F coefficients (every view); engines that keep the S blocks apart: [S blocks] before the
             S chain, [U blocks] after it"""
         r = self.rank
+        if self.p2p:         # the phases store their blocks to the peers and wait for their own arrivals in stream order
+            for ph in (PHASE_F_ALL, PHASE_XTF, PHASE_G_ALL, PHASE_XG, PHASE_S_ALL):
+                self.engine.phase(r, ph, t)
+            return
         self.engine.phase(r, PHASE_F_ALL, t)
         self.engine.phase(r, PHASE_XTF, t)
         self._gather_blocks("GBLOCK")
@@ -664,7 +714,7 @@ class ShardedSweep:
             import torch
             with torch.cuda.stream(self._xstream):      # one context switch per call, not one per broadcast
                 left = n_sweeps
-                if graph_chunk > 0 and self._xstream is self._tstream and n_sweeps >= graph_chunk and not self.sliced:
+                if graph_chunk > 0 and self._xstream is self._tstream and n_sweeps >= graph_chunk and not self.sliced and not self.p2p:
                     left = self._run_graphed(n_sweeps, int(graph_chunk))
                 if left > 0:
                     self._run(left)
@@ -738,6 +788,12 @@ class ShardedSweep:
                     for v in range(self.n_views):
                         if self.replicated[v]:
                             self._bcast(v, "FBLOCK")
+            if self.p2p and not self.sliced:
+                # block form: the first blocks travelled by collectives into the very arenas the sweeps store to -- nobody
+                # stores before every rank's copies have landed (once per run; the sliced form stores to buffers of its own)
+                if self._tstream is not None:
+                    self.engine.synchronize()
+                self.dist.barrier(group=self.group)
         if self.sweeps_done + n_sweeps > self._reserved:
             raise RuntimeError("reserve more sweeps before the first run() (errors are kept per sweep)")
         two_streams = self._tstream is not None and self._xstream is not self._tstream
@@ -758,7 +814,8 @@ class ShardedSweep:
             if hoist and not self._gs_exchanged and not two_streams:
                 # nothing crosses ranks inside the sweep: the rank's whole share in one library call
                 self.engine.phase(self.rank, PHASE_LOCAL_SWEEP, t)
-                self._allgather()
+                if not self.p2p:      # (slice_p2p: the phase stored the own block to the peers itself)
+                    self._allgather()
                 self.sweeps_done += 1
                 continue
             if hoist:

@@ -421,13 +421,12 @@ def build_problem():
     return prob
 
 
-def build_problem_one_view_per_rank(world=2, identity=False, xi=0.4):
+def build_problem_one_view_per_rank(world=2, identity=False, xi=0.4, k=5):
     """One view per rank with equal row counts (equal F exchange blocks): the layout in which the
     blocks travel by one all-gather per sweep.  phi + xi coupled, rows shared at permuted positions."""
     from resnmtf_amd.synth import Problem, planted_view, random_init
     rng = np.random.default_rng(78)
     shapes = [(96, 72 - 8 * v) for v in range(world)]
-    k = 5
     data = [planted_view(n, m, k, 700 + v) for v, (n, m) in enumerate(shapes)]
     inits = [random_init(n, m, k, 800 + v) for v, (n, m) in enumerate(shapes)]
     # identity: every view lists the shared rows in the same order (what auto-naming gives): the F updates
@@ -468,7 +467,7 @@ def main():
     ap.add_argument("--port", type=int, required=True)
     ap.add_argument("--mode", choices=["cpu", "cpu_gs", "gpu", "gpu_gs", "gpu_norep", "gpu_allgather", "gpu_chain", "gpu_chain_off", "gpu_graph1", "gpu_gs_rccl1",
                                        "cpu_slice", "cpu_slice_conv", "gpu_slice", "gpu_slice_conv", "gpu_gs_conv", "gpu_slice_rccl1", "gpu_gs_graph1",
-                                       "gpu_slice_p2p", "gpu_slice_p2p_conv"], required=True)
+                                       "gpu_slice_p2p", "gpu_slice_p2p_conv", "gpu_block_p2p", "gpu_block_p2p_f", "gpu_block_p2p_conv", "gpu_block_p2p_fallback"], required=True)
     ap.add_argument("--n", type=int, default=96)
     ap.add_argument("--m", type=int, default=72)
     ap.add_argument("--tol", type=float, default=1e-6)
@@ -560,6 +559,9 @@ def main():
     if a.mode in ("cpu_slice", "cpu_slice_conv", "gpu_slice", "gpu_slice_conv", "gpu_gs_conv", "gpu_slice_p2p", "gpu_slice_p2p_conv"):
         slice_main(a, dist, sharded)
         return
+    if a.mode.startswith("gpu_block_p2p"):
+        block_main(a, dist, sharded)
+        return
     one_per_rank = a.mode in ("gpu_allgather", "gpu_chain", "gpu_chain_off")
     gs = a.mode in ("cpu_gs", "gpu_gs")
     prob = (build_problem_gs(a.world, a.k) if gs else
@@ -596,6 +598,71 @@ def main():
     drv.close()
     if a.rank == 0:
         out = {"all_error": errs, "mirrors_ok": np.array(mirrors_ok)}
+        for key, lst in res.items():
+            for v, arr in enumerate(lst):
+                out[f"{key}{v}"] = arr
+        np.savez(a.out, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def block_main(a, dist, sharded):
+    """The exchange blocks of the replicated layouts by peer stores (slice_p2p without slice_chains), ranks sharing one GPU:
+    gpu_block_p2p -- F, G and S chains replicated (phi + psi + xi across ranks, rows / columns shared in part);
+    gpu_block_p2p_f -- the F chain alone (phi only, different column counts: BASELINE c3's layout), one exchange per sweep;
+    each against the same layout with its collectives (gloo here): bitwise.  _conv: the convergence loop."""
+    import torch
+    f_only = a.mode == "gpu_block_p2p_f"
+    prob = build_problem_one_view_per_rank(a.world, identity=(a.k % 2 == 1), xi=0.0, k=a.k) if f_only else build_problem_gs(a.world, a.k)
+    n_v = a.world
+    owner_of = list(range(n_v))
+    conv = a.mode.endswith("_conv")
+    extra = {}
+
+    fallback = a.mode.endswith("_fallback")
+    if fallback and a.rank == a.world - 1:      # ONE rank's self-test fails: every rank must end up on the collectives
+        def broken(self, timeout_ms=10000):
+            raise RuntimeError("self-test failure injected by the test")
+        sharded.HipEngineAdapter.p2p_selftest = broken
+
+    def run(p2p):
+        if fallback and p2p:
+            drv = sharded.ShardedSweep.create(prob, owner_of, a.rank, a.world, device_index=0, slice_p2p="auto")
+            p2p = False
+        else:
+            drv = sharded.ShardedSweep.create(prob, owner_of, a.rank, a.world, device_index=0, slice_p2p=("auto" if p2p else False))
+        assert drv.p2p == p2p and not drv.sliced and all(drv.replicated) and drv.replicate_gs == (not f_only)
+        assert drv.collectives_per_sweep == (0 if p2p else 1 if f_only else (2 if drv._s_in_f else 3))
+        if conv:
+            done = drv.run(None, tol=a.tol, max_iters=a.sweeps, check_every=7)
+        else:
+            drv.run(a.sweeps // 2)
+            drv.run(a.sweeps - a.sweeps // 2)          # two calls: state carries over
+            done = a.sweeps
+        drv.engine.synchronize(); torch.cuda.synchronize()
+        kinds = ("F",) if f_only else ("F", "G", "S")
+        raw = [b"".join(drv.engine.factor_tensor(v, kd).cpu().numpy().tobytes() for kd in kinds) for v in range(n_v)]
+        errs = drv.mean_errors()
+        res = drv.gather_results(0)
+        drv.close()
+        return done, raw, errs, res
+
+    done, raw, errs, res = run(True)
+    allr = [None] * a.world
+    dist.all_gather_object(allr, raw)
+    extra["mirrors_ok"] = np.array(all(allr[r][v] == allr[v][v] for r in range(a.world) for v in range(n_v)))
+    if conv:
+        alld = [None] * a.world
+        dist.all_gather_object(alld, int(done))
+        extra["sweeps_done"] = np.array(done)
+        extra["same_stop"] = np.array(len(set(alld)) == 1)
+    else:
+        _, raw2, errs2, _ = run(False)
+        same = [None] * a.world
+        dist.all_gather_object(same, bool(raw == raw2 and np.array_equal(errs, errs2)))
+        extra["bitwise_vs_collectives"] = np.array(all(same))
+    if a.rank == 0:
+        out = {"all_error": errs, **extra}
         for key, lst in res.items():
             for v, arr in enumerate(lst):
                 out[f"{key}{v}"] = arr

@@ -54,11 +54,11 @@ def oracle_reference(sweeps=12):
                             row_names=prob.row_names, col_names=prob.col_names, n_iters=sweeps)
 
 
-def oracle_reference_one_view_per_rank(world=2, sweeps=12, identity=False, xi=0.4):
+def oracle_reference_one_view_per_rank(world=2, sweeps=12, identity=False, xi=0.4, k=5):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dist_worker
     from oracle import resnmtf_oracle as O
-    prob = dist_worker.build_problem_one_view_per_rank(world, identity=identity, xi=xi)
+    prob = dist_worker.build_problem_one_view_per_rank(world, identity=identity, xi=xi, k=k)
     return O.res_nmtf_inner(prob.data, prob.init_f, prob.init_s, prob.init_g, prob.phi, prob.xi, prob.psi,
                             row_names=prob.row_names, col_names=prob.col_names, n_iters=sweeps)
 
@@ -530,3 +530,54 @@ def test_sharded_hip_peer_stores_convergence_mode(tmp_path):
     assert bool(got["same_stop"])
     done = int(got["sweeps_done"])
     assert done < 600 and abs(done - len(ref["All_Error"])) <= 2, (done, len(ref["All_Error"]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# slice_p2p without slice_chains: the exchange blocks of the REPLICATED layouts by peer stores + stream-waited arrival counters
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,k,uneven", [(2, 5, False), (3, 24, False), (4, 32, False), (3, 57, True), (2, 64, False)])
+def test_sharded_hip_replicated_chains_peer_stores(tmp_path, world, k, uneven, monkeypatch):
+    """F, G and S chains replicated (phi + psi + xi across ranks, rows / columns shared in part and at different positions --
+    a layout the sliced chains do not cover): the T blocks behind the Xt.F pass and the U rows + S block behind the X.G pass
+    are stored straight into every peer's arena, G_ALL / S_ALL wait for their V arrivals.  Bitwise the all-gather form, every
+    rank's copies bitwise the owner's, results against the oracle.  uneven: F blocks of different sizes (S blocks apart)."""
+    if uneven:
+        monkeypatch.setenv("RESNMTF_TEST_UNEVEN", "1")
+    got = launch("gpu_block_p2p", tmp_path, world=world, k=k, sweeps=14)
+    assert bool(got["bitwise_vs_collectives"]) and bool(got["mirrors_ok"])
+    ref = oracle_reference_gs(world, sweeps=14, k=k)
+    np.testing.assert_allclose(got["all_error"], ref["All_Error"], atol=2e-5, rtol=1e-4)
+    for v in range(world):
+        assert rel_fro(got[f"output_f{v}"], ref["output_f"][v]) < 2e-5
+        assert rel_fro(got[f"output_g{v}"], ref["output_g"][v]) < 2e-5
+        assert rel_fro(got[f"output_s{v}"], ref["output_s"][v]) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,k", [(2, 5), (3, 6), (4, 16)])
+def test_sharded_hip_replicated_f_chain_peer_stores(tmp_path, world, k):
+    """phi only, different column counts (BASELINE c3's layout): one exchange per sweep -- the own F block (U rows, F
+    coefficients, lambda) stored to the peers behind the X.G pass, after every rank has acknowledged reading the previous
+    one.  Bitwise the all-gather form; against the oracle.  Odd k: rows in the same order (fused F chain), even: permuted."""
+    got = launch("gpu_block_p2p_f", tmp_path, world=world, k=k, sweeps=15, xi=0.0)
+    assert bool(got["bitwise_vs_collectives"]) and bool(got["mirrors_ok"])
+    ref = oracle_reference_one_view_per_rank(world, sweeps=15, identity=(k % 2 == 1), xi=0.0, k=k)
+    np.testing.assert_allclose(got["all_error"], ref["All_Error"], atol=2e-5, rtol=1e-4)
+    for v in range(world):
+        assert rel_fro(got[f"output_f{v}"], ref["output_f"][v]) < 2e-5
+        assert rel_fro(got[f"output_g{v}"], ref["output_g"][v]) < 2e-5
+
+
+@pytest.mark.gpu
+def test_sharded_hip_replicated_chains_peer_stores_convergence(tmp_path):
+    got = launch("gpu_block_p2p_conv", tmp_path, world=3, k=7, sweeps=600, extra=("--tol", 1e-6))
+    assert bool(got["same_stop"]) and bool(got["mirrors_ok"])
+    assert int(got["sweeps_done"]) < 600
+
+
+@pytest.mark.gpu
+def test_sharded_peer_stores_auto_falls_back_on_every_rank(tmp_path):
+    """ShardedSweep.create(slice_p2p="auto"): when the library's self-test fails on ONE rank (injected), every rank closes its
+    peer-store engine and builds the same layout with its collectives -- same decision everywhere, results unchanged."""
+    got = launch("gpu_block_p2p_fallback", tmp_path, world=3, k=6, sweeps=9)
+    assert bool(got["bitwise_vs_collectives"]) and bool(got["mirrors_ok"])
