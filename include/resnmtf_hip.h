@@ -186,7 +186,15 @@ typedef struct resnmtf_options {
                              (any channel), resnmtf_p2p_import for every rank (the own one included), a host barrier, then ONE
                              resnmtf_prepare.  Receive buffers are single: the order of the sweep itself keeps a writer one
                              exchange behind its reader.  Tested with 2-4 processes on one GPU (IPC on one
-                             device); not yet run across GPUs */
+                             device); not yet run across GPUs: resnmtf_p2p_selftest tells whether a node can run it.
+                             WITHOUT slice_chains (block form; needs replicate_f, one owned view = slice_index, slice_count =
+                             number of views <= 8): the exchange blocks of the replicated layouts are stored into every peer's
+                             arena instead of all-gathered -- replicate_gs: behind RESNMTF_PHASE_XTF (T rows + G coefficients) and
+                             RESNMTF_PHASE_XG (U rows + S block), G_ALL / S_ALL wait for the V arrivals of their sweep;
+                             replicate_f alone: the sweep is RESNMTF_PHASE_LOCAL_SWEEP, which waits for the V blocks of the
+                             previous sweep, acknowledges them after its F chain and stores its own block after V
+                             acknowledgements.  The first blocks (after resnmtf_prepare) travel by the caller's collective,
+                             followed by a synchronise + barrier before the first phase */
   int xcd_order;          /* 1 (opt-in): the main workgroups of the k > 16 passes renumbered so that every XCD works through a
                              contiguous range of the split-major list -- a row split's B block is then fetched into one or two
                              L2s instead of all eight (c5 Xt.F: 154 MB of 1.78 GB per launch).  Measured (tools/round3/xcd_ab.sh):

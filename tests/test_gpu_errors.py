@@ -93,8 +93,19 @@ def test_sliced_layout_options_are_checked():
         Engine([60, 60], [40, 40], [3, 3], owned=[True, True], **base)
     with pytest.raises(ResnmtfError, match="slice_count"):
         Engine([60, 60, 60], [40, 40, 40], [3, 3, 3], owned=[True, False, False], **base)
-    with pytest.raises(ResnmtfError, match="slice_p2p needs slice_chains"):
+    with pytest.raises(ResnmtfError, match="slice_p2p needs slice_chains or the replicated chains"):
         Engine([60], [40], [3], slice_p2p=True)
+    with pytest.raises(ResnmtfError, match="exactly one owned view"):          # block form: one view per rank as well
+        Engine([60, 60], [40, 30], [3, 3], replicate_f=True, slice_p2p=True, slice_index=0, slice_count=2)
+    with pytest.raises(ResnmtfError, match="slice_count"):
+        Engine([60, 60], [40, 30], [3, 3], owned=[True, False], replicate_f=True, slice_p2p=True, slice_index=0, slice_count=3)
+    blk = Engine([60, 60], [40, 30], [3, 3], owned=[True, False], replicate_f=True, slice_p2p=True, slice_index=0, slice_count=2)
+    with pytest.raises(ResnmtfError, match="import every rank"):
+        blk.p2p_selftest(100)                              # nothing mapped yet
+    blk.p2p_import(0)
+    with pytest.raises(ResnmtfError, match="import every rank"):
+        blk.prepare()
+    blk.close()
     prob = synth.make_problem([(60, 40), (60, 40)], 3, phi=1.0, psi=1.0)
     e = Engine([60, 60], [40, 40], [3, 3], owned=[True, False], slice_p2p=True, **base)
     assert e.slice_info() == (32, 32)
