@@ -256,16 +256,21 @@ def run_sharded(args) -> dict:
     # outside the timed region, and is reported in config.
     want = os.environ.get("RESNMTF_P2P", "auto")
     use_p2p, p2p_note, force_slice = False, "collectives (RESNMTF_P2P=0)", None
+    # RESNMTF_P2P_GRAPH=1 (opt-in): the waits as one-wave kernels, the sweeps replayed from a captured graph.  Measured with one
+    # rank (tools/round3/p2p_one_rank.sh): 52.8 us per sweep replayed against 52.4 us with plain launches and stream waits -- the
+    # sweep is not bound by the host's launch sequence, so the default keeps the command-processor waits
+    p2p_graph = os.environ.get("RESNMTF_P2P_GRAPH", "0") == "1"
+    p2p_chunk = max(c for c in range(1, 33) if args.steps % c == 0) if p2p_graph else 0
     if want == "1":
         use_p2p, p2p_note = True, "peer stores (RESNMTF_P2P=1)"
     elif want == "auto" and world > 1:
-        probe = _make_driver(sharded, prob, n_views, rank, world, local_rank, slice_p2p="auto")
+        probe = _make_driver(sharded, prob, n_views, rank, world, local_rank, slice_p2p="auto", p2p_graph=p2p_graph)
         if not probe.p2p:
             p2p_note = "collectives (no peer-store form for this layout, or the self-test failed: see stderr)"
             probe.close()
         else:
             force_slice = probe.sliced
-            probe.reserve(16); probe.run(5)
+            probe.reserve(16); probe.run(5, graph_chunk=(5 if p2p_graph else 0))      # (the form the timed run uses)
             tab_p = probe.view_error_table()
             probe.close()
             ref = _make_driver(sharded, prob, n_views, rank, world, local_rank, slice_p2p=False, slice_chains=force_slice)
@@ -275,12 +280,16 @@ def run_sharded(args) -> dict:
             use_p2p = bool(np.array_equal(tab_p, tab_c) and np.isfinite(tab_p).all())
             p2p_note = ("peer stores (self-test passed; 5 sweeps bitwise equal to the collective exchange on this node)" if use_p2p else
                         "collectives (peer stores disagreed with the collective exchange on this node)")
-    drv = _make_driver(sharded, prob, n_views, rank, world, local_rank, slice_p2p=use_p2p, slice_chains=force_slice)
+    drv = _make_driver(sharded, prob, n_views, rank, world, local_rank, slice_p2p=use_p2p, slice_chains=force_slice,
+                       **({"p2p_graph": True} if (use_p2p and p2p_graph) else {}))
     if os.environ.get("RESNMTF_FORCE_BCAST") == "1":      # rehearsal: issue the F broadcast even with one rank
         drv.plan[0]["F"] = True
     drv.reserve(args.warmup + args.steps + 8)      # per-sweep error slots for both run() calls
     # RESNMTF_SHARDED_GRAPH=K (opt-in, RCCL only): K sweeps incl. their collectives replayed from one captured graph
     chunk = int(os.environ.get("RESNMTF_SHARDED_GRAPH", "0")) if backend == "nccl" else 0
+    if use_p2p and p2p_graph:
+        chunk = p2p_chunk
+    captured = drv.precapture(chunk) if chunk > 0 else False      # (set-up: the timed run only replays)
     drv.run(args.warmup, graph_chunk=chunk)
     drv.collect()
     dist.barrier(); torch.cuda.synchronize()
@@ -390,7 +399,7 @@ def run_sharded(args) -> dict:
                                + " (all rows / columns of coupled views shared), one view per GPU, Gauss-Seidel order kept exactly; " + layout,
                    "n_views": n_views, "shapes": [list(sh) for sh in shapes], "k": k,
                    "backend": ("rccl" if backend == "nccl" else backend), "world_size": world, "distinct_devices": n_devices,
-                   "exchange": p2p_note,
+                   "exchange": p2p_note, "sweeps_per_graph_replay": (chunk if captured else 0),
                    "final_error": float(errs[-1]) if len(errs) else None,
                    "scaling_note": "BASELINE.json prescribes a different workload per GPU count (c3 / c4 / c5): compare value / n_gpus "
                                    "with the one-view rate of the same shape (roofline.single_view_updates_per_s), not across N"},

@@ -194,7 +194,12 @@ typedef struct resnmtf_options {
                              replicate_f alone: the sweep is RESNMTF_PHASE_LOCAL_SWEEP, which waits for the V blocks of the
                              previous sweep, acknowledges them after its F chain and stores its own block after V
                              acknowledgements.  The first blocks (after resnmtf_prepare) travel by the caller's collective,
-                             followed by a synchronise + barrier before the first phase */
+                             followed by a synchronise + barrier before the first phase.
+                             2: as 1 with every wait as a one-wave KERNEL instead of hipStreamWaitValue32 (device counters number
+                             the waits, the spin sleeps between polls and is bounded: resnmtf_synchronize reports a wait that gave
+                             up) -- kernel nodes only, so whole sweeps can be captured in a graph and replayed by the caller.
+                             Bitwise the same results (tested in all three layouts); measured no faster than 1 (the sweep is not
+                             bound by the host's launches): opt-in */
   int xcd_order;          /* 1 (opt-in): the main workgroups of the k > 16 passes renumbered so that every XCD works through a
                              contiguous range of the split-major list -- a row split's B block is then fetched into one or two
                              L2s instead of all eight (c5 Xt.F: 154 MB of 1.78 GB per launch).  Measured (tools/round3/xcd_ab.sh):

@@ -685,8 +685,15 @@ void p2p_signal(resnmtf_handle* h, int e) {
   for (int c = 0; c < h->V; ++c) a.flag[c] = h->peers[(size_t)c].flags + e;
   hipLaunchKernelGGL(slice_signal_kernel, dim3(1), dim3(64), 0, h->stream, a);
 }
-hipError_t p2p_wait(resnmtf_handle* h, int e, unsigned int arrivals) {
-  return hipStreamWaitValue32(h->stream, h->p2p_flags + e, arrivals, hipStreamWaitValueGte, 0xFFFFFFFFu);
+// the stream goes on when counter e has V * (waits of this call site so far + add) arrivals.  slice_p2p = 1: the command
+// processor waits (hipStreamWaitValue32; the host's sweep index numbers the wait); 2: p2p_wait_kernel (site counters on the device)
+hipError_t p2p_wait(resnmtf_handle* h, int e, int site, int sweep, int add) {
+  if (h->opt.slice_p2p != 2)
+    return hipStreamWaitValue32(h->stream, h->p2p_flags + e, (unsigned)h->V * (unsigned)(sweep + add), hipStreamWaitValueGte, 0xFFFFFFFFu);
+  P2pWaitArgs a{};
+  a.flag = h->p2p_flags + e; a.site = h->p2p_flags + 16 + site; a.per_wait = (unsigned)h->V; a.add = (unsigned)add; a.err = h->fuse_err_dev;
+  hipLaunchKernelGGL(p2p_wait_kernel, dim3(1), dim3(64), 0, h->stream, a);
+  return hipGetLastError();
 }
 // block_p2p: byte ranges [off0, off0 + b0) and [off1, off1 + b1) of this rank's part of an arena -> the same place on every peer
 // kind 0: F exchange arena, 1: G exchange arena, 2: S block arena
@@ -2440,12 +2447,12 @@ int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep) {
         // peer-store form of the one-exchange layout: the F chain waits for the V blocks stored after sweep t - 1 (the first
         // ones travel by the caller's collective after resnmtf_prepare), says so to every rank once it has read them, and the
         // own block of this sweep is stored only after every rank has said so (the ack has long arrived: two passes lie between)
-        if (sweep > 0) HIP_TRY(h, p2p_wait(h, 0, (unsigned)h->V * (unsigned)sweep));
+        if (sweep > 0 || h->opt.slice_p2p == 2) HIP_TRY(h, p2p_wait(h, 0, 0, sweep, 0));
         enqueue_phase_f_all(h);
         p2p_signal(h, 1);
         for (const auto& w : h->views)
           if (w.owned) enqueue_phase_g(h, w, -1.0, false);
-        HIP_TRY(h, p2p_wait(h, 1, (unsigned)h->V * (unsigned)(sweep + 1)));
+        HIP_TRY(h, p2p_wait(h, 1, 1, sweep, 1));
         for (const auto& w : h->views)
           if (w.owned) push_f_block(h, w);
         p2p_signal(h, 0);
@@ -2462,7 +2469,7 @@ int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep) {
       if (h->block_p2p) { push_g_block(h, vs); p2p_signal(h, 1); }
       break;
     case RESNMTF_PHASE_G_ALL:
-      if (h->block_p2p) HIP_TRY(h, p2p_wait(h, 1, (unsigned)h->V * (unsigned)(sweep + 1)));
+      if (h->block_p2p) HIP_TRY(h, p2p_wait(h, 1, 2, sweep, 1));
       if (h->wchain_ok[1]) { launch_wide_chain(h, 1, checked); break; }
       if (enqueue_g_chain(h, checked)) break;
       for (const auto& w : h->views)
@@ -2476,28 +2483,28 @@ int resnmtf_phase(resnmtf_handle* h, int v, int phase, int sweep) {
     // feeds it are in, and ends with one arrival on every rank's counter of the exchange it fed with peer stores.
     // Arrivals so far: U + S blocks V (t + 2) after sweep t's X.G (the run prologue is the first), the others V (t + 1).
     case RESNMTF_PHASE_S_ALL:
-      if (h->opt.slice_p2p) HIP_TRY(h, p2p_wait(h, 0, (unsigned)h->V * (unsigned)(sweep + (h->block_p2p ? 1 : 2))));
+      if (h->opt.slice_p2p) HIP_TRY(h, p2p_wait(h, 0, 3, sweep, h->block_p2p ? 1 : 2));
       if (int rc = launch_s_chain(h, checked)) return rc;
       break;
     case RESNMTF_PHASE_SLICE_F:
-      if (h->opt.slice_p2p) HIP_TRY(h, p2p_wait(h, 0, (unsigned)h->V * (unsigned)(sweep + 1)));
+      if (h->opt.slice_p2p) HIP_TRY(h, p2p_wait(h, 0, 4, sweep, 1));
       launch_wide_chain(h, 0, checked, true);
       if (h->opt.slice_p2p) p2p_signal(h, 1);
       break;
     case RESNMTF_PHASE_SLICE_XTF:
-      if (h->opt.slice_p2p) HIP_TRY(h, p2p_wait(h, 1, (unsigned)h->V * (unsigned)(sweep + 1)));
+      if (h->opt.slice_p2p) HIP_TRY(h, p2p_wait(h, 1, 5, sweep, 1));
       launch_slice_unpack(h, vs, 0, checked);
       launch_pass(h, vs, false, 1, tol, checked);
       launch_slice_pack(h, vs, false, checked);
       if (h->opt.slice_p2p) p2p_signal(h, 2);
       break;
     case RESNMTF_PHASE_SLICE_G:
-      if (h->opt.slice_p2p) HIP_TRY(h, p2p_wait(h, 2, (unsigned)h->V * (unsigned)(sweep + 1)));
+      if (h->opt.slice_p2p) HIP_TRY(h, p2p_wait(h, 2, 6, sweep, 1));
       launch_wide_chain(h, 1, checked, true);
       if (h->opt.slice_p2p) p2p_signal(h, 3);
       break;
     case RESNMTF_PHASE_SLICE_XG:
-      if (h->opt.slice_p2p) HIP_TRY(h, p2p_wait(h, 3, (unsigned)h->V * (unsigned)(sweep + 1)));
+      if (h->opt.slice_p2p) HIP_TRY(h, p2p_wait(h, 3, 7, sweep, 1));
       launch_slice_unpack(h, vs, 1, checked);
       launch_pass(h, vs, true, 1, tol, checked);
       launch_slice_pack(h, vs, true, checked);
@@ -2901,7 +2908,7 @@ int resnmtf_p2p_selftest(resnmtf_handle* h, int timeout_ms) {
     HIP_TRY(h, hipMemset(mine, 0, kWords * sizeof(unsigned int)));
   }
   // 3. the stream wait the phases use sees the counter
-  HIP_TRY(h, p2p_wait(h, kProbeFlag, want));
+  HIP_TRY(h, hipStreamWaitValue32(h->stream, h->p2p_flags + kProbeFlag, want, hipStreamWaitValueGte, 0xFFFFFFFFu));
   for (;;) {
     const hipError_t q = hipStreamQuery(h->stream);
     if (q == hipSuccess) break;
@@ -2941,6 +2948,10 @@ int resnmtf_synchronize(resnmtf_handle* h) {
   if (!h) return RESNMTF_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->opt.device_id));
   if (int rc = sync_both(h)) return rc;
+  if (h->fuse_err && *h->fuse_err == 2) {
+    *h->fuse_err = 0;
+    return h->fail(RESNMTF_ERR_HIP, "a peer-store wait gave up (p2p_wait_kernel: the arrivals of an exchange never came): results are invalid");
+  }
   if (h->fuse_err && *h->fuse_err) {
     *h->fuse_err = 0;
     return h->fail(RESNMTF_ERR_HIP, "a fused pass launch gave up waiting for its update blocks (pass_fused_kernel): results are invalid");

@@ -75,7 +75,7 @@ class Engine:
         opts.slice_index = int(slice_index)
         opts.slice_count = int(slice_count)
         opts.fuse_updates = int(fuse_updates)
-        opts.slice_p2p = 1 if slice_p2p else 0
+        opts.slice_p2p = int(slice_p2p)          # (True = 1: stream waits; 2: wait kernels, graph-capturable)
         opts.xcd_order = 1 if xcd_order else 0
         nr = np.asarray(self.n_rows, dtype=np.int32)
         nc = np.asarray(self.n_cols, dtype=np.int32)

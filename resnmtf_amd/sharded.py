@@ -331,6 +331,9 @@ class ShardedSweep:
         want_gs = engine_opts.pop("replicate_gs", None)
         want_slice = engine_opts.pop("slice_chains", None)
         self.p2p = bool(engine_opts.pop("slice_p2p", False))
+        # peer stores with the waits as one-wave kernels (resnmtf_options.slice_p2p = 2): whole sweeps can then be captured in a
+        # graph and replayed (run(graph_chunk=...) / precapture) -- no host launch sequence per sweep
+        self._p2p_graph = bool(engine_opts.pop("p2p_graph", False)) and self.p2p
         self._overlap_u = bool(engine_opts.pop("overlap_u", True))
         gs_coupled = any(p["G"] or p["S"] for p in self.plan)
         k_all = [f.shape[1] for f in prob.init_f]
@@ -379,9 +382,10 @@ class ShardedSweep:
                 # block form: the exchange blocks of the replicated layouts by peer stores (one view per rank, every view replicated)
                 if not (all(self.replicated) and self.owner_of == list(range(world)) and self.n_views == world and world <= 8):
                     raise ValueError("slice_p2p needs the sliced or the replicated-chains layout with one view per rank (<= 8)")
-                engine_opts = dict(engine_opts, slice_index=rank, slice_count=world, slice_p2p=True)
+                engine_opts = dict(engine_opts, slice_index=rank, slice_count=world, slice_p2p=(2 if self._p2p_graph else 1))
             if self.sliced:
-                engine_opts = dict(engine_opts, slice_chains=True, slice_index=rank, slice_count=world, slice_p2p=self.p2p)
+                engine_opts = dict(engine_opts, slice_chains=True, slice_index=rank, slice_count=world,
+                                   slice_p2p=((2 if self._p2p_graph else 1) if self.p2p else 0))
             self.engine = make_hip_engine(prob, self.owned, device_index, self._tstream.cuda_stream,
                                           replicate_f=any(self.replicated), replicate_gs=self.replicate_gs, **engine_opts)
         self.sweeps_done = 0
@@ -714,13 +718,27 @@ class ShardedSweep:
             import torch
             with torch.cuda.stream(self._xstream):      # one context switch per call, not one per broadcast
                 left = n_sweeps
-                if graph_chunk > 0 and self._xstream is self._tstream and n_sweeps >= graph_chunk and not self.sliced and not self.p2p:
+                if graph_chunk > 0 and self._xstream is self._tstream and n_sweeps >= graph_chunk and self._graphable():
                     left = self._run_graphed(n_sweeps, int(graph_chunk))
                 if left > 0:
                     self._run(left)
             return n_sweeps
         self._run(n_sweeps)
         return n_sweeps
+
+    def _graphable(self) -> bool:
+        """Sweeps that can be captured: the one-stream collective layouts other than the sliced one (RCCL), and every
+        peer-store layout whose waits are kernels (p2p_graph)."""
+        return self._p2p_graph if self.p2p else not self.sliced
+
+    def precapture(self, graph_chunk: int):
+        """Run prologue + capture of a ``graph_chunk``-sweep graph now (set-up), so that a later run() only replays."""
+        if graph_chunk <= 0 or self._tstream is None or self._xstream is not self._tstream or not self._graphable():
+            return False
+        import torch
+        with torch.cuda.stream(self._xstream):
+            self._run_graphed(0, int(graph_chunk))
+        return True
 
     def _run_to_convergence(self, tol: float, max_iters: int, check_every: int) -> int:
         if not self.replicate_gs:

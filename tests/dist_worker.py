@@ -474,6 +474,7 @@ def main():
     ap.add_argument("--sweeps", type=int, default=12)
     ap.add_argument("--xi", type=float, default=0.4)
     ap.add_argument("--k", type=int, default=5)
+    ap.add_argument("--graph", type=int, default=0)      # peer-store modes: sweeps replayed from captured graphs of this many
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -630,15 +631,18 @@ def block_main(a, dist, sharded):
             drv = sharded.ShardedSweep.create(prob, owner_of, a.rank, a.world, device_index=0, slice_p2p="auto")
             p2p = False
         else:
-            drv = sharded.ShardedSweep.create(prob, owner_of, a.rank, a.world, device_index=0, slice_p2p=("auto" if p2p else False))
+            drv = sharded.ShardedSweep.create(prob, owner_of, a.rank, a.world, device_index=0, slice_p2p=("auto" if p2p else False),
+                                              **({"p2p_graph": True} if (p2p and a.graph) else {}))
+        chunk = a.graph if p2p else 0
         assert drv.p2p == p2p and not drv.sliced and all(drv.replicated) and drv.replicate_gs == (not f_only)
         assert drv.collectives_per_sweep == (0 if p2p else 1 if f_only else (2 if drv._s_in_f else 3))
         if conv:
             done = drv.run(None, tol=a.tol, max_iters=a.sweeps, check_every=7)
         else:
-            drv.run(a.sweeps // 2)
-            drv.run(a.sweeps - a.sweeps // 2)          # two calls: state carries over
+            drv.run(a.sweeps // 2, graph_chunk=chunk)
+            drv.run(a.sweeps - a.sweeps // 2, graph_chunk=chunk)          # two calls: state carries over
             done = a.sweeps
+            assert not chunk or len(getattr(drv, "_graphs", {})) == 1
         drv.engine.synchronize(); torch.cuda.synchronize()
         kinds = ("F",) if f_only else ("F", "G", "S")
         raw = [b"".join(drv.engine.factor_tensor(v, kd).cpu().numpy().tobytes() for kd in kinds) for v in range(n_v)]
@@ -697,7 +701,8 @@ def slice_main(a, dist, sharded):
         return errs, res, raw
 
     p2p = "p2p" in a.mode
-    drv = make(a.mode != "gpu_gs_conv", kk_mode=2, **({"slice_p2p": True} if p2p else {}))
+    drv = make(a.mode != "gpu_gs_conv", kk_mode=2, **({"slice_p2p": True, "p2p_graph": bool(a.graph)} if p2p else {}))
+    chunk = a.graph if p2p else 0
     assert drv.sliced == (a.mode != "gpu_gs_conv") and drv.replicate_gs and drv.p2p == p2p
     assert not p2p or drv.collectives_per_sweep == 0
     if conv:
@@ -707,8 +712,9 @@ def slice_main(a, dist, sharded):
         dist.all_gather_object(alld, int(done))
         extra["same_stop"] = np.array(len(set(alld)) == 1)
     else:
-        drv.run(a.sweeps // 2)
-        drv.run(a.sweeps - a.sweeps // 2)          # two calls: state carries over
+        drv.run(a.sweeps // 2, graph_chunk=chunk)
+        drv.run(a.sweeps - a.sweeps // 2, graph_chunk=chunk)          # two calls: state carries over
+        assert not chunk or len(getattr(drv, "_graphs", {})) == 1
     errs, res, raw = results(drv)
     drv.close()
     if a.mode in ("gpu_slice", "gpu_slice_p2p"):   # the same run with the chains REPLICATED (same hand-off mode) / p2p: with the

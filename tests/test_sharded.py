@@ -581,3 +581,15 @@ def test_sharded_peer_stores_auto_falls_back_on_every_rank(tmp_path):
     peer-store engine and builds the same layout with its collectives -- same decision everywhere, results unchanged."""
     got = launch("gpu_block_p2p_fallback", tmp_path, world=3, k=6, sweeps=9)
     assert bool(got["bitwise_vs_collectives"]) and bool(got["mirrors_ok"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,world,k,extra", [("gpu_block_p2p_f", 2, 5, ()), ("gpu_block_p2p", 3, 24, ()),
+                                                ("gpu_slice_p2p", 3, 40, ("--n", 301, "--m", 97))])
+def test_sharded_peer_stores_replayed_from_graphs(tmp_path, mode, world, k, extra):
+    """resnmtf_options.slice_p2p = 2: the waits of the phases are one-wave kernels (device counters number them), so the sweeps --
+    stores, signals and waits included -- are captured once and replayed (3-sweep graphs + eager remainders here).  Bitwise
+    the eager collective form, in each of the three peer-store layouts."""
+    got = launch(mode, tmp_path, world=world, k=k, sweeps=14, xi=(0.0 if mode.endswith("_f") else 0.4), extra=("--graph", 3, *extra))
+    key = "bitwise_vs_replicated" if mode == "gpu_slice_p2p" else "bitwise_vs_collectives"
+    assert bool(got[key])
