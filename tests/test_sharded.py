@@ -421,7 +421,7 @@ def test_sliceable_layouts():
     assert not sharded.sliceable(uneq, [0, 1], 2)
 
 
-@pytest.mark.parametrize("world,n,m", [(2, 96, 72), (3, 96, 72), (4, 26, 50)])
+@pytest.mark.parametrize("world,n,m", [(2, 96, 72), (3, 96, 72), (4, 26, 50), (8, 200, 72)])
 def test_sliced_chains_schedule_matches_oracle_gloo_cpu(tmp_path, world, n, m):
     """The driver's sliced sweep (F chain on my rows, [new F rows], own Xt.F, [T slices], G chain on my columns, [new G
     rows], own X.G, [S blocks] S chain || [U slices]; one all-to-all per exchange, a final collect of the fp64 slices) with
