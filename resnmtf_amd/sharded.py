@@ -278,6 +278,22 @@ def local_problem(n_views: int, shape, k: int, phi: float = 0.0, xi: float = 0.0
     return prob
 
 
+_ROLE_STREAMS: Dict[tuple, object] = {}
+
+
+def _role_stream(device_index: int, role: str):
+    """One stream per (device, role) and process, shared by the drivers created one after the other (a bench builds several):
+    every new stream is another hardware queue for the scheduler to map, and queues left behind by closed drivers were
+    measured to halve the rate of three processes sharing one GPU (runlist oversubscription).  Drivers alive at the same
+    time on one device merely share the queue."""
+    import torch
+    key = (int(device_index), role)
+    st = _ROLE_STREAMS.get(key)
+    if st is None:
+        st = _ROLE_STREAMS[key] = torch.cuda.Stream(device=device_index)
+    return st
+
+
 class P2PUnavailable(RuntimeError):
     """The peer-store exchange cannot be used (layout or node); raised on every rank alike."""
 
@@ -376,8 +392,8 @@ class ShardedSweep:
         else:
             import torch
             torch.cuda.set_device(device_index)
-            self._tstream = torch.cuda.Stream(device=device_index)
-            self._xstream = self._tstream if self._serial else torch.cuda.Stream(device=device_index)
+            self._tstream = _role_stream(device_index, "compute")
+            self._xstream = self._tstream if self._serial else _role_stream(device_index, "exchange")
             if self.p2p and not self.sliced:
                 # block form: the exchange blocks of the replicated layouts by peer stores (one view per rank, every view replicated)
                 if not (all(self.replicated) and self.owner_of == list(range(world)) and self.n_views == world and world <= 8):
@@ -436,7 +452,7 @@ class ShardedSweep:
         elif self.sliced and self._tstream is not None and self._overlap_u and dist.get_backend(group) == "nccl":
             import torch
             self._group_u = dist.new_group(ranks=list(range(world)), backend="nccl")      # collective: every rank gets here
-            self._ustream = torch.cuda.Stream(device=device_index)
+            self._ustream = _role_stream(device_index, "u_exchange")
             self._ev_u, self._ev_xg = torch.cuda.Event(), torch.cuda.Event()
         # S blocks inside the F blocks (the HIP library with equal-shaped views): two collectives per sweep instead of three
         self._s_in_f = bool(self.replicate_gs and getattr(self.engine, "sblock_in_fblock", False))
