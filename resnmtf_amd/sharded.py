@@ -426,13 +426,33 @@ class ShardedSweep:
             # nobody signals before everybody has mapped and zeroed
             if self._tstream is None or not hasattr(self.engine, "p2p_export"):
                 raise ValueError("slice_p2p needs the HIP engine")
-            mine = self.engine.p2p_export()
+            # Every step that can fail on one rank only (export, mapping, the probes) is followed by a gather of every rank's
+            # outcome before anybody acts on it: all ranks leave together, with the same exception, and nothing is hung on.
+            def agree(problem: Optional[str]):
+                outcomes: List[Optional[str]] = [None] * world
+                dist.all_gather_object(outcomes, problem, group=group)
+                failed = [o for o in outcomes if o]
+                if failed:
+                    dist.barrier(group=group)      # nobody unmaps while a peer may still be probing
+                    self.engine.close()
+                    raise P2PUnavailable("; ".join(failed))
+
+            problem, mine = None, b""
+            try:
+                mine = self.engine.p2p_export()
+            except Exception as exc:
+                problem = f"rank {rank}: {exc}"
             everyone: List[Optional[bytes]] = [None] * world
             dist.all_gather_object(everyone, mine, group=group)
-            for r in range(world):
-                self.engine.p2p_import(r, b"" if r == rank else everyone[r])
-            dist.barrier(group=group)
-            # probe stores / arrivals / the stream wait under host-side deadlines; every rank learns every rank's outcome
+            if problem is None and all(everyone):
+                try:
+                    for r in range(world):
+                        self.engine.p2p_import(r, b"" if r == rank else everyone[r])
+                except Exception as exc:
+                    problem = f"rank {rank}: {exc}"
+            agree(problem)
+            dist.barrier(group=group)              # everybody has mapped everybody
+            # probe stores / arrivals / the stream wait under host-side deadlines (resnmtf_p2p_selftest)
             problem = None
             if not self.sliced and not self.replicate_gs and not (self._allgather_blocks and not any(p["G"] or p["S"] for p in self.plan)):
                 problem = ("slice_p2p with the replicated F chain alone needs the one-exchange layout (equal F blocks, "
@@ -442,13 +462,7 @@ class ShardedSweep:
                     self.engine.p2p_selftest(10000)
                 except Exception as exc:      # (ResnmtfError: reported, never hung on)
                     problem = f"rank {rank}: {exc}"
-            outcomes: List[Optional[str]] = [None] * world
-            dist.all_gather_object(outcomes, problem, group=group)
-            failed = [o for o in outcomes if o]
-            if failed:
-                dist.barrier(group=group)      # nobody unmaps while a peer may still be probing
-                self.engine.close()
-                raise P2PUnavailable("; ".join(failed))
+            agree(problem)
         elif self.sliced and self._tstream is not None and self._overlap_u and dist.get_backend(group) == "nccl":
             import torch
             self._group_u = dist.new_group(ranks=list(range(world)), backend="nccl")      # collective: every rank gets here

@@ -621,10 +621,13 @@ def block_main(a, dist, sharded):
     extra = {}
 
     fallback = a.mode.endswith("_fallback")
-    if fallback and a.rank == a.world - 1:      # ONE rank's self-test fails: every rank must end up on the collectives
-        def broken(self, timeout_ms=10000):
-            raise RuntimeError("self-test failure injected by the test")
-        sharded.HipEngineAdapter.p2p_selftest = broken
+    if fallback and a.rank == a.world - 1:      # ONE rank's self-test (odd k) / mapping (even k) fails: every rank must end up on the collectives
+        def broken(self, *args, **kw):
+            raise RuntimeError("failure injected by the test")
+        if a.k % 2:
+            sharded.HipEngineAdapter.p2p_selftest = broken
+        else:
+            sharded.HipEngineAdapter.p2p_import = broken
 
     def run(p2p):
         if fallback and p2p:

@@ -576,10 +576,12 @@ def test_sharded_hip_replicated_chains_peer_stores_convergence(tmp_path):
 
 
 @pytest.mark.gpu
-def test_sharded_peer_stores_auto_falls_back_on_every_rank(tmp_path):
-    """ShardedSweep.create(slice_p2p="auto"): when the library's self-test fails on ONE rank (injected), every rank closes its
-    peer-store engine and builds the same layout with its collectives -- same decision everywhere, results unchanged."""
-    got = launch("gpu_block_p2p_fallback", tmp_path, world=3, k=6, sweeps=9)
+@pytest.mark.parametrize("k", [6, 7])
+def test_sharded_peer_stores_auto_falls_back_on_every_rank(tmp_path, k):
+    """ShardedSweep.create(slice_p2p="auto"): when mapping a peer's buffers (k = 6) or the library's self-test (k = 7) fails on
+    ONE rank (injected), every rank closes its peer-store engine and builds the same layout with its collectives -- same
+    decision everywhere, nobody left waiting, results unchanged."""
+    got = launch("gpu_block_p2p_fallback", tmp_path, world=3, k=k, sweeps=9)
     assert bool(got["bitwise_vs_collectives"]) and bool(got["mirrors_ok"])
 
 
