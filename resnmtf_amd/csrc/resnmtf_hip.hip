@@ -157,6 +157,7 @@ struct resnmtf_handle {
   bool p2p_ready = false, p2p_prepared = false;
   unsigned int probe_epoch = 0;       // resnmtf_p2p_selftest calls so far (its arrival counter is cumulative)
   bool block_p2p = false;             // slice_p2p without slice_chains: the exchange blocks of the replicated layouts by peer stores
+  double* slice_nd = nullptr;         // sliced chains in two launches: num | den of every view on this rank's slice (slice_products_kernel)
   WideChainArgs<8> schain[2]{};       // SLICE_F ([0]) / SLICE_G ([1])
   int schain_grid[2] = {0, 0};
   double ktime_ms[RESNMTF_TIMED_KINDS] = {0, 0, 0, 0, 0, 0};     // time_kernels: per kind (resnmtf_kernel_timings)
@@ -567,6 +568,29 @@ void launch_wide_chain(resnmtf_handle* h, int g, bool checked, bool sliced = fal
   const int groups16_all = ceil_div(c.len, 16);
   const int n_slots = h->n_cu * (int)std::max<size_t>(1, std::min<size_t>(kMaxLds / slice_chain_smem_bytes(KP, c.n_views <= 4 ? 4 : 8), 2048 / (16 * KP)));
   const bool slice_wide = slice_env ? slice_env[0] == '1' : groups16_all > n_slots;
+  // ... and the 16-row form itself in two launches (slice_products_kernel: every (group, pair of views) a workgroup of its own;
+  // slice_walk_kernel: the element-wise chain), unless RESNMTF_SLICE_FUSED=1 keeps it in one (slice_chain_kernel) -- same bits
+  // Measured (tools/round3/slice_split_ab.sh): c5 x 8, G slice (8 views, k = 64, 63 groups) 36.0 -> 22.4 us; c4 x 4 (4 views,
+  // k = 32: two short product stages) 11.2 -> 15.2 / 9.4 -> 10.5 us -- the second launch costs more than the stages it spreads.
+  // So: more than two pairs of views and k > 32; RESNMTF_SLICE_FUSED=1 / =0 forces one form.
+  static const char* fused_env = std::getenv("RESNMTF_SLICE_FUSED");
+  const bool split_form = fused_env ? fused_env[0] == '0' : (c.n_views > 4 && KP > 32);
+  if (sliced && !slice_wide && h->slice_nd && split_form) {
+    const int groups16 = ceil_div(c.len, 16);
+    const unsigned nd_stride = (unsigned)groups16 * 16u * (unsigned)KP;
+    const dim3 gridp(groups16, (c.n_views + 1) / 2), gridw(groups16), block16(16 * KP);
+#define SLSPLIT(KPV, NVBV, ARGS) do { \
+    LAUNCH_TIMED(h, kind, (slice_products_kernel<KPV, NVBV>), gridp, block16, 0, ARGS, h->slice_nd, nd_stride); \
+    LAUNCH_TIMED(h, kind, (slice_walk_kernel<KPV, NVBV>), gridw, block16, 0, ARGS, (const double*)h->slice_nd, nd_stride); } while (0)
+#define SLSPLIT_K(NVBV, ARGS) do { \
+    switch (KP) { case 16: SLSPLIT(16, NVBV, ARGS); break; case 32: SLSPLIT(32, NVBV, ARGS); break; \
+                  case 48: SLSPLIT(48, NVBV, ARGS); break; default: SLSPLIT(64, NVBV, ARGS); break; } } while (0)
+    if (c.n_views <= 4) { WideChainArgs<4> a4 = narrow_wchain<4>(c); SLSPLIT_K(4, a4); }
+    else { SLSPLIT_K(8, c); }
+#undef SLSPLIT_K
+#undef SLSPLIT
+    return;
+  }
   if (sliced && !slice_wide) {
     const int groups16 = ceil_div(c.len, 16);
     const dim3 grid16(groups16), block16(16 * KP);          // (one row group per workgroup)
@@ -1253,6 +1277,8 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     }
     if ((e = dev_alloc_zero(&h->f_send, (size_t)V * h->sl_rows * v0.KP)) != hipSuccess) return bail(e, "hipMalloc slice exchange buffers");
     if ((e = dev_alloc_zero(&h->f_recv, (size_t)V * h->sl_rows * v0.KP)) != hipSuccess) return bail(e, "hipMalloc slice exchange buffers");
+    if ((e = dev_alloc_zero(&h->slice_nd, (size_t)V * 2 * (size_t)round_up(std::max(h->sl_rows, h->sl_cols), 16) * v0.KP)) != hipSuccess)
+      return bail(e, "hipMalloc slice product scratch");
     if ((e = dev_alloc_zero(&h->g_send, (size_t)V * h->sl_cols * v0.KP)) != hipSuccess) return bail(e, "hipMalloc slice exchange buffers");
     if ((e = dev_alloc_zero(&h->g_recv, (size_t)V * h->sl_cols * v0.KP)) != hipSuccess) return bail(e, "hipMalloc slice exchange buffers");
   }
@@ -1434,7 +1460,7 @@ int resnmtf_destroy(resnmtf_handle* h) {
   for (auto& pc : h->peers)
     for (void* q : pc.opened)
       if (q) (void)hipIpcCloseMemHandle(q);
-  for (void* p : {(void*)h->p2p_flags, (void*)h->view_sweep, (void*)h->u_send, (void*)h->u_recv, (void*)h->t_send, (void*)h->t_recv, (void*)h->f_send,
+  for (void* p : {(void*)h->slice_nd, (void*)h->p2p_flags, (void*)h->view_sweep, (void*)h->u_send, (void*)h->u_recv, (void*)h->t_send, (void*)h->t_recv, (void*)h->f_send,
                   (void*)h->f_recv, (void*)h->g_send, (void*)h->g_recv})
     if (p) (void)hipFree(p);
   if (h->ctl) (void)hipFree(h->ctl);

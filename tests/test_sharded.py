@@ -469,6 +469,25 @@ def test_sharded_hip_sliced_chains(tmp_path, world, k, n, m):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,k,n,m,force", [(3, 16, 700, 200, True), (3, 40, 301, 97, True), (2, 64, 1000, 330, True), (4, 57, 90, 64, True),
+                                               (6, 64, 400, 150, False), (5, 48, 333, 97, False)])
+def test_sharded_hip_sliced_chains_two_launch_form(tmp_path, world, k, n, m, force, monkeypatch):
+    """The sliced chains as slice_products_kernel (every (16-row group, pair of views) a workgroup of its own) +
+    slice_walk_kernel (the element-wise chain): chosen by the library for more than four views at k > 32 (the last two cases:
+    six and five ranks on the one GPU), forced here for the smaller layouts (RESNMTF_SLICE_FUSED=0).  Bitwise the replicated
+    chains, like the one-launch form; odd view counts, ragged and empty slices."""
+    if force:
+        monkeypatch.setenv("RESNMTF_SLICE_FUSED", "0")
+    got = launch("gpu_slice", tmp_path, world=world, k=k, sweeps=10, extra=("--n", n, "--m", m), timeout=900)
+    assert bool(got["bitwise_vs_replicated"])
+    ref = oracle_reference_slice(world, sweeps=10, k=k, n=n, m=m)
+    np.testing.assert_allclose(got["all_error"], ref["All_Error"], atol=2e-5, rtol=1e-4)
+    for v in range(world):
+        assert rel_fro(got[f"output_f{v}"], ref["output_f"][v]) < 2e-5
+        assert rel_fro(got[f"output_g{v}"], ref["output_g"][v]) < 2e-5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode,world,k", [("gpu_slice_conv", 3, 24), ("gpu_slice_conv", 2, 64), ("gpu_gs_conv", 3, 7)])
 def test_sharded_hip_convergence_mode(tmp_path, mode, world, k):
     """Convergence mode (R/main.r:50-81) in the view-sharded layouts with a replicated S chain: the stop test runs on the
