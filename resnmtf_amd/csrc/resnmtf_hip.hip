@@ -578,10 +578,10 @@ void launch_wide_chain(resnmtf_handle* h, int g, bool checked, bool sliced = fal
   if (sliced && !slice_wide && h->slice_nd && split_form) {
     const int groups16 = ceil_div(c.len, 16);
     const unsigned nd_stride = (unsigned)groups16 * 16u * (unsigned)KP;
-    const dim3 gridp(groups16, (c.n_views + 1) / 2), gridw(groups16), block16(16 * KP);
+    const dim3 gridp(groups16, (c.n_views + 1) / 2), gridw(ceil_div(c.len, 4)), block16(16 * KP), blockw(4 * KP);
 #define SLSPLIT(KPV, NVBV, ARGS) do { \
     LAUNCH_TIMED(h, kind, (slice_products_kernel<KPV, NVBV>), gridp, block16, 0, ARGS, h->slice_nd, nd_stride); \
-    LAUNCH_TIMED(h, kind, (slice_walk_kernel<KPV, NVBV>), gridw, block16, 0, ARGS, (const double*)h->slice_nd, nd_stride); } while (0)
+    LAUNCH_TIMED(h, kind, (slice_walk_kernel<KPV, NVBV, 4>), gridw, blockw, 0, ARGS, (const double*)h->slice_nd, nd_stride); } while (0)
 #define SLSPLIT_K(NVBV, ARGS) do { \
     switch (KP) { case 16: SLSPLIT(16, NVBV, ARGS); break; case 32: SLSPLIT(32, NVBV, ARGS); break; \
                   case 48: SLSPLIT(48, NVBV, ARGS); break; default: SLSPLIT(64, NVBV, ARGS); break; } } while (0)
