@@ -470,11 +470,11 @@ def test_sharded_hip_sliced_chains(tmp_path, world, k, n, m):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,k,n,m,force", [(3, 16, 700, 200, True), (3, 40, 301, 97, True), (2, 64, 1000, 330, True), (4, 57, 90, 64, True),
-                                               (6, 64, 400, 150, False), (5, 48, 333, 97, False)])
+                                               (5, 64, 400, 150, False), (5, 48, 333, 97, False)])
 def test_sharded_hip_sliced_chains_two_launch_form(tmp_path, world, k, n, m, force, monkeypatch):
     """The sliced chains as slice_products_kernel (every (16-row group, pair of views) a workgroup of its own) +
     slice_walk_kernel (the element-wise chain): chosen by the library for more than four views at k > 32 (the last two cases:
-    six and five ranks on the one GPU), forced here for the smaller layouts (RESNMTF_SLICE_FUSED=0).  Bitwise the replicated
+    five ranks on the one GPU -- with the test runner's own process the six the box allows), forced here for the smaller layouts (RESNMTF_SLICE_FUSED=0).  Bitwise the replicated
     chains, like the one-launch form; odd view counts, ragged and empty slices."""
     if force:
         monkeypatch.setenv("RESNMTF_SLICE_FUSED", "0")
