@@ -922,3 +922,88 @@ class ShardedSweep:
                 self.engine.synchronize()
             self.dist.barrier(group=self.group)
         self.engine.close()
+
+
+def res_nmtf_inner(data, row_indices=None, column_indices=None, init_f=None, init_s=None, init_g=None,
+                   k_vec=None, phi=None, xi=None, psi=None, n_iters=None, *, rank: int, world: int,
+                   owner_of: Optional[Sequence[int]] = None, row_names=None, col_names=None, device_index: Optional[int] = None,
+                   group=None, tol: float = 1.0e-6, max_iters: int = 100000, no_clusts: bool = False, dst: int = 0,
+                   slice_p2p="auto", **driver_opts):
+    """``res_nmtf_inner`` (``R/main.r:32-140``, the explicit-init entry) over the ranks of a process group, one call per rank:
+    the view-sharded counterpart of ``resnmtf_amd.api.res_nmtf_inner`` with the same arguments and the same return value
+    (on rank ``dst``; ``None`` on the others).
+
+    ``data[v]`` is needed only on the rank that owns view v (``owner_of[v]``, default ``v % world``) and may be ``None``
+    elsewhere; the initial factors of EVERY view are needed on every rank (they are small, and the replicated chains start
+    from them).  ``n_iters=None`` runs the reference's convergence loop (``R/main.r:50-81``): on the device when the layout
+    has the replicated S chain (every rank stops on the same sweep), otherwise sweep by sweep with the error gathered after
+    each.  ``row_indices`` / ``column_indices`` are accepted for signature parity; the shared-name maps are rebuilt from
+    ``row_names`` / ``col_names`` (``naming.shared_names``), as ``api.res_nmtf_inner`` does when they are ``None``."""
+    n_v = len(init_f) if init_f is not None else 0
+    if not n_v or init_s is None or init_g is None or len(init_s) != n_v or len(init_g) != n_v:
+        raise ValueError("the view-sharded entry needs explicit initial factors of every view on every rank")
+    data = list(data)
+    if len(data) != n_v:
+        raise ValueError("data must have one entry per view (None for views this rank does not own)")
+    k_all = [int(np.asarray(f).shape[1]) for f in init_f]
+    if k_vec is not None and [int(k) for k in np.atleast_1d(k_vec)] != k_all:
+        raise ValueError("k_vec does not match the initial factors")
+    if len(set(k_all)) != 1:
+        raise ValueError("the view-sharded path needs the same k in every view")
+    owner_of = [v % world for v in range(n_v)] if owner_of is None else list(owner_of)
+    for v in range(n_v):
+        if owner_of[v] == rank and data[v] is None:
+            raise ValueError(f"rank {rank} owns view {v} but was not given its data")
+    shapes = [(np.asarray(f).shape[0], np.asarray(g).shape[0]) for f, g in zip(init_f, init_g)]
+    zeros = np.zeros((n_v, n_v))
+    prob = Problem([None if d is None else np.asarray(d, dtype=np.float64) for d in data],
+                   [np.asarray(x, dtype=np.float64) for x in init_f], [np.asarray(x, dtype=np.float64) for x in init_s],
+                   [np.asarray(x, dtype=np.float64) for x in init_g],
+                   zeros if phi is None else np.asarray(phi, dtype=np.float64), zeros if xi is None else np.asarray(xi, dtype=np.float64),
+                   zeros if psi is None else np.asarray(psi, dtype=np.float64), k_all[0], "res_nmtf_inner (view-sharded)")
+    if row_names is None or col_names is None:      # the reference's auto-naming (R/utils.r:482-491) from the shapes alone
+        stand_in = [np.broadcast_to(0.0, sh) for sh in shapes]      # (shape only: no memory behind it)
+        rn, cn = naming.give_names(stand_in, prob.phi if prob.phi.any() else None, prob.psi if prob.psi.any() else None)
+        row_names, col_names = row_names or rn, col_names or cn
+    prob.row_names, prob.col_names = [list(x) for x in row_names], [list(x) for x in col_names]
+    prob.extras["shapes"] = shapes
+    if "engine_factory" in driver_opts or "engine" in driver_opts:
+        drv = ShardedSweep(prob, owner_of, rank, world, group=group, **driver_opts)
+    else:
+        drv = ShardedSweep.create(prob, owner_of, rank, world, slice_p2p=slice_p2p, group=group,
+                                  device_index=(rank if device_index is None else device_index), **driver_opts)
+    try:
+        if n_iters is not None:
+            drv.reserve(int(n_iters) + 8)
+            drv.run(int(n_iters))
+            errs = drv.mean_errors()
+        elif drv.replicate_gs:
+            drv.run(None, tol=tol, max_iters=max_iters)
+            errs = drv.mean_errors()
+        else:      # no replicated S chain to hold the stop test: one sweep, one look (R/main.r:55,77-80)
+            drv.reserve(max_iters + 8)
+            prev = None
+            while drv.sweeps_done < max_iters:
+                drv.run(1)
+                errs = drv.mean_errors()
+                if prev is not None and not (abs(errs[-1] - prev) > tol):
+                    break
+                prev = errs[-1]
+        res = drv.gather_results(dst)
+        lm = {v: drv.engine.get_factors(v)[3:5] for v in range(n_v) if drv.owned[v]} if hasattr(drv.engine, "get_factors") else {}
+        everyone: List[Optional[dict]] = [None] * world
+        drv.dist.all_gather_object(everyone, lm, group=group)
+    finally:
+        drv.close()
+    if rank != dst:
+        return None
+    if no_clusts:                                                                                 # main.r:115-120
+        return {k: res[k] for k in ("output_f", "output_s", "output_g")}
+    lam_mu = {}
+    for part in everyone:
+        lam_mu.update(part or {})
+    error = float(np.mean(errs[-10:])) if n_iters is None else float(errs[-1])                    # main.r:127 / :129
+    return {"output_f": res["output_f"], "output_s": res["output_s"], "output_g": res["output_g"],
+            "Error": error, "All_Error": np.asarray(errs), "bisil": None,
+            "row_clusters": res["row_clusters"], "col_clusters": res["col_clusters"],
+            "lambda": [lam_mu.get(v, (None, None))[0] for v in range(n_v)], "mu": [lam_mu.get(v, (None, None))[1] for v in range(n_v)]}

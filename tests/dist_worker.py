@@ -467,7 +467,7 @@ def main():
     ap.add_argument("--port", type=int, required=True)
     ap.add_argument("--mode", choices=["cpu", "cpu_gs", "gpu", "gpu_gs", "gpu_norep", "gpu_allgather", "gpu_chain", "gpu_chain_off", "gpu_graph1", "gpu_gs_rccl1",
                                        "cpu_slice", "cpu_slice_conv", "gpu_slice", "gpu_slice_conv", "gpu_gs_conv", "gpu_slice_rccl1", "gpu_gs_graph1",
-                                       "gpu_slice_p2p", "gpu_slice_p2p_conv", "gpu_block_p2p", "gpu_block_p2p_f", "gpu_block_p2p_conv", "gpu_block_p2p_fallback"], required=True)
+                                       "gpu_slice_p2p", "gpu_slice_p2p_conv", "gpu_block_p2p", "gpu_block_p2p_f", "gpu_block_p2p_conv", "gpu_block_p2p_fallback", "cpu_api", "cpu_api_conv", "gpu_api", "gpu_api_conv"], required=True)
     ap.add_argument("--n", type=int, default=96)
     ap.add_argument("--m", type=int, default=72)
     ap.add_argument("--tol", type=float, default=1e-6)
@@ -563,6 +563,9 @@ def main():
     if a.mode.startswith("gpu_block_p2p"):
         block_main(a, dist, sharded)
         return
+    if "_api" in a.mode:
+        api_main(a, dist, sharded)
+        return
     one_per_rank = a.mode in ("gpu_allgather", "gpu_chain", "gpu_chain_off")
     gs = a.mode in ("cpu_gs", "gpu_gs")
     prob = (build_problem_gs(a.world, a.k) if gs else
@@ -601,6 +604,33 @@ def main():
         out = {"all_error": errs, "mirrors_ok": np.array(mirrors_ok)}
         for key, lst in res.items():
             for v, arr in enumerate(lst):
+                out[f"{key}{v}"] = arr
+        np.savez(a.out, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def api_main(a, dist, sharded):
+    """sharded.res_nmtf_inner -- the reference's entry point over the ranks of a group: stand-in engine on CPU (three views
+    with names shared in part, two of them on one rank when world = 2) / HIP engines sharing the one GPU (one view per rank)."""
+    conv = a.mode.endswith("_conv")
+    if a.mode.startswith("cpu"):
+        prob = build_problem()
+        opts = {"engine_factory": lambda p, owned: OracleEngine(p, owned)}
+    else:
+        prob = build_problem_gs(a.world, a.k)
+        opts = {"device_index": 0}
+    n_v = len(prob.init_f)
+    owner_of = [v % a.world for v in range(n_v)]
+    data = [d if owner_of[v] == a.rank else None for v, d in enumerate(prob.data)]      # a rank holds only its own views
+    res = sharded.res_nmtf_inner(data, None, None, prob.init_f, prob.init_s, prob.init_g, None, prob.phi, prob.xi, prob.psi,
+                                 None if conv else a.sweeps, rank=a.rank, world=a.world, owner_of=owner_of,
+                                 row_names=prob.row_names, col_names=prob.col_names, tol=a.tol, max_iters=a.sweeps, **opts)
+    assert (res is None) == (a.rank != 0)
+    if a.rank == 0:
+        out = {"all_error": res["All_Error"], "Error": np.array(res["Error"])}
+        for key in ("output_f", "output_s", "output_g", "row_clusters", "col_clusters"):
+            for v, arr in enumerate(res[key]):
                 out[f"{key}{v}"] = arr
         np.savez(a.out, **out)
     dist.barrier()

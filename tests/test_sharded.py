@@ -614,3 +614,51 @@ def test_sharded_peer_stores_replayed_from_graphs(tmp_path, mode, world, k, extr
     got = launch(mode, tmp_path, world=world, k=k, sweeps=14, xi=(0.0 if mode.endswith("_f") else 0.4), extra=("--graph", 3, *extra))
     key = "bitwise_vs_replicated" if mode == "gpu_slice_p2p" else "bitwise_vs_collectives"
     assert bool(got[key])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sharded.res_nmtf_inner: the reference's entry point (R/main.r:32-140) over the ranks of a process group
+def _oracle_inner(prob, **kw):
+    from oracle import resnmtf_oracle as O
+    return O.res_nmtf_inner(prob.data, prob.init_f, prob.init_s, prob.init_g, prob.phi, prob.xi, prob.psi,
+                            row_names=prob.row_names, col_names=prob.col_names, **kw)
+
+
+@pytest.mark.parametrize("mode", ["cpu_api", "cpu_api_conv"])
+def test_sharded_res_nmtf_inner_gloo_cpu(tmp_path, mode):
+    """Fixed sweeps and the convergence loop (here sweep by sweep: the layout has no replicated S chain) with the exact-fp64
+    stand-in engine, two ranks: the reference's return value -- factors after normalisation_check, cluster matrices, All_Error,
+    Error (last value / mean of the last ten, R/main.r:127-129) -- equals the sequential oracle's."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_worker
+    conv = mode.endswith("_conv")
+    got = launch(mode, tmp_path, world=2, sweeps=(400 if conv else 12), extra=("--tol", 1e-5))
+    ref = _oracle_inner(dist_worker.build_problem(), **({"tol": 1e-5, "max_iters": 400} if conv else {"n_iters": 12}))
+    assert len(got["all_error"]) == len(ref["All_Error"]) and (not conv or len(ref["All_Error"]) < 400)
+    np.testing.assert_allclose(got["all_error"], ref["All_Error"], rtol=1e-10, atol=1e-12)
+    want_error = float(np.mean(ref["All_Error"][-10:])) if conv else float(ref["All_Error"][-1])
+    assert abs(float(got["Error"]) - want_error) < 1e-12
+    for v in range(3):
+        assert rel_fro(got[f"output_f{v}"], ref["output_f"][v]) < 1e-11
+        assert rel_fro(got[f"output_g{v}"], ref["output_g"][v]) < 1e-11
+        assert np.array_equal(got[f"row_clusters{v}"], ref["row_clusters"][v])
+        assert np.array_equal(got[f"col_clusters{v}"], ref["col_clusters"][v])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,world,k", [("gpu_api", 3, 7), ("gpu_api_conv", 2, 24)])
+def test_sharded_res_nmtf_inner_hip(tmp_path, mode, world, k):
+    """The same entry point with the HIP engines (ranks share the one GPU; exchange form chosen by the self-test): against the
+    oracle, fixed sweeps and the device-side convergence loop."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_worker
+    conv = mode.endswith("_conv")
+    got = launch(mode, tmp_path, world=world, k=k, sweeps=(600 if conv else 12), extra=("--tol", 1e-6))
+    ref = _oracle_inner(dist_worker.build_problem_gs(world, k), **({"tol": 1e-6, "max_iters": 600} if conv else {"n_iters": 12}))
+    if conv:
+        assert abs(len(got["all_error"]) - len(ref["All_Error"])) <= 2 and len(got["all_error"]) < 600
+    else:
+        np.testing.assert_allclose(got["all_error"], ref["All_Error"], atol=2e-5, rtol=1e-4)
+        for v in range(world):
+            assert rel_fro(got[f"output_f{v}"], ref["output_f"][v]) < 2e-5
+            assert rel_fro(got[f"output_g{v}"], ref["output_g"][v]) < 2e-5
