@@ -280,8 +280,10 @@ def run_sharded(args) -> dict:
             use_p2p = bool(np.array_equal(tab_p, tab_c) and np.isfinite(tab_p).all())
             p2p_note = ("peer stores (self-test passed; 5 sweeps bitwise equal to the collective exchange on this node)" if use_p2p else
                         "collectives (peer stores disagreed with the collective exchange on this node)")
-    drv = _make_driver(sharded, prob, n_views, rank, world, local_rank, slice_p2p=use_p2p, slice_chains=force_slice,
+    drv = _make_driver(sharded, prob, n_views, rank, world, local_rank, slice_p2p=(True if want == "1" else "auto" if use_p2p else False), slice_chains=force_slice,
                        **({"p2p_graph": True} if (use_p2p and p2p_graph) else {}))
+    if use_p2p and not drv.p2p:      # (the self-test runs again for every engine: same outcome on every rank)
+        use_p2p, p2p_note = False, "collectives (the self-test failed when the timed driver was built)"
     if os.environ.get("RESNMTF_FORCE_BCAST") == "1":      # rehearsal: issue the F broadcast even with one rank
         drv.plan[0]["F"] = True
     drv.reserve(args.warmup + args.steps + 8)      # per-sweep error slots for both run() calls
@@ -317,7 +319,7 @@ def run_sharded(args) -> dict:
     kt = None
     t_steps = max(2, min(args.steps, 30))
     try:
-        drv_t = _make_driver(sharded, prob, n_views, rank, world, local_rank, time_kernels=True, slice_p2p=use_p2p, slice_chains=force_slice)
+        drv_t = _make_driver(sharded, prob, n_views, rank, world, local_rank, time_kernels=True, slice_p2p=(True if want == "1" else "auto" if use_p2p else False), slice_chains=force_slice)
         drv_t.reserve(t_steps + 8)
         drv_t.run(2)
         torch.cuda.synchronize()
