@@ -15,6 +15,6 @@ except Exception as e:
     print("$name: no line", e)
 PY
 }
-run p2p_graph RESNMTF_P2P=1
-run p2p_eager RESNMTF_P2P=1 RESNMTF_P2P_GRAPH=0
+run p2p_graph RESNMTF_P2P=1 RESNMTF_P2P_GRAPH=1
+run p2p_eager RESNMTF_P2P=1
 run collective RESNMTF_P2P=0
