@@ -412,9 +412,11 @@ int resnmtf_loop_state(resnmtf_handle* h, int* sweeps_done, int* done, int* stop
  * map rank `rank`'s (for the own rank `handles` is ignored).  After every rank is imported the slice phases store to the peers. */
 int resnmtf_p2p_export(resnmtf_handle* h, void* handles, size_t capacity, size_t* bytes);
 int resnmtf_p2p_import(resnmtf_handle* h, int rank, const void* handles, size_t bytes);
-/* slice_p2p: called by every rank at about the same time, after all imports and a host barrier, before resnmtf_prepare --
- * 1 KB of peer stores into every rank's receive buffers, one arrival on every rank's probe counter, then (host-side polls,
- * all bounded by timeout_ms; <= 0: 10 s) the V arrivals, the stored words, and the stream wait the phases use.  An error
+/* slice_p2p: called by every rank at about the same time, after all imports and a host barrier, before resnmtf_prepare.
+ * Two rounds of: 1 KB of peer stores into every rank's receive buffers + one arrival on every rank's probe counter; the host
+ * polls its counter for the V arrivals; the stream wait the phases use, then a KERNEL reads the stored words (the second
+ * round re-reads lines the first left in this device's caches: a wait + launch that does not drop them shows here); an
+ * acknowledgement round.  Every wait is a host-side poll bounded by timeout_ms (<= 0: 10 s): nothing can hang.  An error
  * return (text in resnmtf_last_error) means this node cannot run the peer-store exchange: create the handles without it. */
 int resnmtf_p2p_selftest(resnmtf_handle* h, int timeout_ms);
 /* slice_chains: rows / columns per slice (multiples of 32; slice r covers [r * per_slice, min((r + 1) * per_slice, n))). */

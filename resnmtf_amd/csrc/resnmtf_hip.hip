@@ -2897,57 +2897,76 @@ int resnmtf_p2p_selftest(resnmtf_handle* h, int timeout_ms) {
     if (h->block_p2p) return reinterpret_cast<unsigned int*>(f_arena + (static_cast<const char*>(h->views[(size_t)from].fblk) - static_cast<const char*>(h->fblk_arena)));
     return reinterpret_cast<unsigned int*>(u_recv + (size_t)from * h->u_chunk);
   };
-  P2pProbeArgs a{};
-  a.tag = 0xA5000000u | ((unsigned)r << 16) | ((h->probe_epoch & 0xFFu) << 8);
-  for (int c = 0; c < V; ++c)
-    if (c != r) a.dst[a.n_dst++] = region(h->peers[(size_t)c].fblk_arena, h->peers[(size_t)c].u_recv, r);
-  if (a.n_dst) hipLaunchKernelGGL(p2p_probe_kernel, dim3(1), dim3(kWords), 0, h->stream, a);
-  p2p_signal(h, kProbeFlag);
-  HIP_TRY(h, hipGetLastError());
-  const unsigned int want = (unsigned)V * (h->probe_epoch + 1);
-  h->probe_epoch += 1;
-  // 1. the V arrivals (remote system-scope atomics on this rank's counter), polled from the host
-  unsigned int seen = 0;
-  for (;;) {
-    HIP_TRY(h, hipMemcpy(&seen, h->p2p_flags + kProbeFlag, sizeof(seen), hipMemcpyDeviceToHost));
-    if (seen >= want) break;
-    if (std::chrono::steady_clock::now() > deadline) {
-      char msg[160];
-      std::snprintf(msg, sizeof(msg), "slice_p2p self-test: %u of %u arrivals within the deadline (peer atomics do not reach this rank)", seen, want);
-      return h->fail(RESNMTF_ERR_HIP, msg);
-    }
-    std::this_thread::sleep_for(std::chrono::milliseconds(1));
-  }
-  // 2. what the peers stored before they signalled is here
-  std::vector<unsigned int> got((size_t)kWords);
-  for (int c = 0; c < V; ++c) {
-    if (c == r) continue;
-    unsigned int* mine = region(static_cast<char*>(h->fblk_arena), h->u_recv, c);
-    HIP_TRY(h, hipMemcpy(got.data(), mine, kWords * sizeof(unsigned int), hipMemcpyDeviceToHost));
-    const unsigned int tag = 0xA5000000u | ((unsigned)c << 16) | (((h->probe_epoch - 1) & 0xFFu) << 8);
-    for (int i = 0; i < kWords; ++i)
-      if (got[(size_t)i] != (tag | (unsigned)i)) {
-        char msg[160];
-        std::snprintf(msg, sizeof(msg), "slice_p2p self-test: word %d from rank %d reads %08x after its arrival (peer stores not visible)", i, c, got[(size_t)i]);
+  // host-side waits, all under the one deadline
+  auto poll_flag = [&](int flag, unsigned int want, const char* what) -> int {
+    unsigned int seen = 0;
+    for (;;) {
+      HIP_TRY(h, hipMemcpy(&seen, h->p2p_flags + flag, sizeof(seen), hipMemcpyDeviceToHost));
+      if (seen >= want) return RESNMTF_OK;
+      if (std::chrono::steady_clock::now() > deadline) {
+        char msg[200];
+        std::snprintf(msg, sizeof(msg), "slice_p2p self-test: %u of %u %s within the deadline (peer atomics do not reach this rank)", seen, want, what);
         return h->fail(RESNMTF_ERR_HIP, msg);
       }
-    HIP_TRY(h, hipMemset(mine, 0, kWords * sizeof(unsigned int)));
-  }
-  // 3. the stream wait the phases use sees the counter
-  HIP_TRY(h, hipStreamWaitValue32(h->stream, h->p2p_flags + kProbeFlag, want, hipStreamWaitValueGte, 0xFFFFFFFFu));
-  for (;;) {
-    const hipError_t q = hipStreamQuery(h->stream);
-    if (q == hipSuccess) break;
-    if (q != hipErrorNotReady) return h->fail_hip("hipStreamQuery", q);
-    if (std::chrono::steady_clock::now() > deadline) {
-      // last resort so that the handle can still be destroyed: satisfy the wait from the host (the counter is only probed again
-      // by a later self-test, which would then pass this step at once -- the error below is what the caller acts on)
-      const unsigned int all = 0x7FFFFFFFu;
-      (void)hipMemcpy(h->p2p_flags + kProbeFlag, &all, sizeof(all), hipMemcpyHostToDevice);
-      return h->fail(RESNMTF_ERR_HIP, "slice_p2p self-test: hipStreamWaitValue32 does not see the arrival counter");
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));
     }
-    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  };
+  auto drain_stream = [&](int flag) -> int {
+    for (;;) {
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q == hipSuccess) return RESNMTF_OK;
+      if (q != hipErrorNotReady) return h->fail_hip("hipStreamQuery", q);
+      if (std::chrono::steady_clock::now() > deadline) {
+        // last resort so that the handle can still be destroyed: satisfy the wait from the host (the error is what the caller acts on)
+        const unsigned int all = 0x7FFFFFFFu;
+        (void)hipMemcpy(h->p2p_flags + flag, &all, sizeof(all), hipMemcpyHostToDevice);
+        return h->fail(RESNMTF_ERR_HIP, "slice_p2p self-test: hipStreamWaitValue32 does not see the arrival counter");
+      }
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+  };
+  int* bad = nullptr; int* bad_dev = nullptr;
+  HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&bad), sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+  *bad = 0;
+  struct Guard { int* p; ~Guard() { if (p) (void)hipHostFree(p); } } guard{bad};
+  HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&bad_dev), bad, 0));
+  const int kAckFlag = 9;
+  // Two rounds with different words.  Each: store to every peer + one arrival on every rank's counter; the host sees the V
+  // arrivals; the stream wait of the phases + a kernel that reads what arrived (as in a sweep -- the second round reads lines
+  // the first left in this device's caches); an acknowledgement round so that nobody overwrites what a peer has not read yet.
+  for (int round = 0; round < 2; ++round) {
+    const unsigned int step = 2u * h->probe_epoch + (unsigned)round;
+    auto tag_of = [&](int rank) { return 0xA5000000u | ((unsigned)rank << 16) | ((step & 0xFFu) << 8); };
+    P2pProbeArgs a{};
+    a.tag = tag_of(r);
+    for (int c = 0; c < V; ++c)
+      if (c != r) a.dst[a.n_dst++] = region(h->peers[(size_t)c].fblk_arena, h->peers[(size_t)c].u_recv, r);
+    if (a.n_dst) hipLaunchKernelGGL(p2p_probe_kernel, dim3(1), dim3(kWords), 0, h->stream, a);
+    p2p_signal(h, kProbeFlag);
+    HIP_TRY(h, hipGetLastError());
+    const unsigned int want = (unsigned)V * (step + 1);
+    if (int rc = poll_flag(kProbeFlag, want, "arrivals")) return rc;
+    HIP_TRY(h, hipStreamWaitValue32(h->stream, h->p2p_flags + kProbeFlag, want, hipStreamWaitValueGte, 0xFFFFFFFFu));
+    P2pCheckArgs ck{};
+    for (int c = 0; c < V; ++c)
+      if (c != r) { ck.src[ck.n_src] = region(static_cast<char*>(h->fblk_arena), h->u_recv, c); ck.tag[ck.n_src++] = tag_of(c); }
+    ck.bad = bad_dev;
+    if (ck.n_src) hipLaunchKernelGGL(p2p_check_kernel, dim3(1), dim3(kWords), 0, h->stream, ck);
+    HIP_TRY(h, hipGetLastError());
+    if (int rc = drain_stream(kProbeFlag)) return rc;
+    if (*bad) {
+      char msg[200];
+      std::snprintf(msg, sizeof(msg), "slice_p2p self-test: %d words read by a kernel after the stream wait are not what the peers stored (round %d%s)",
+                    *bad, round, round ? ": stale cache lines" : "");
+      return h->fail(RESNMTF_ERR_HIP, msg);
+    }
+    p2p_signal(h, kAckFlag);                                   // "I have read round `round`"
+    HIP_TRY(h, hipGetLastError());
+    if (int rc = poll_flag(kAckFlag, want, "acknowledgements")) return rc;
   }
+  h->probe_epoch += 1;
+  for (int c = 0; c < V; ++c)
+    if (c != r) HIP_TRY(h, hipMemset(region(static_cast<char*>(h->fblk_arena), h->u_recv, c), 0, kWords * sizeof(unsigned int)));
   return RESNMTF_OK;
 }
 
