@@ -256,6 +256,7 @@ def run_sharded(args) -> dict:
     # outside the timed region, and is reported in config.
     want = os.environ.get("RESNMTF_P2P", "auto")
     use_p2p, p2p_note, force_slice = False, "collectives (RESNMTF_P2P=0)", None
+    tab_ref = None                                 # per-view errors of the first sweeps by the collective exchange
     # RESNMTF_P2P_GRAPH=1 (opt-in): the waits as one-wave kernels, the sweeps replayed from a captured graph.  Measured with one
     # rank (tools/round3/p2p_one_rank.sh): 52.8 us per sweep replayed against 52.4 us with plain launches and stream waits -- the
     # sweep is not bound by the host's launch sequence, so the default keeps the command-processor waits
@@ -275,7 +276,7 @@ def run_sharded(args) -> dict:
             probe.close()
             ref = _make_driver(sharded, prob, n_views, rank, world, local_rank, slice_p2p=False, slice_chains=force_slice)
             ref.reserve(16); ref.run(5)
-            tab_c = ref.view_error_table()
+            tab_c = tab_ref = ref.view_error_table()
             ref.close()
             use_p2p = bool(np.array_equal(tab_p, tab_c) and np.isfinite(tab_p).all())
             p2p_note = ("peer stores (self-test passed; 5 sweeps bitwise equal to the collective exchange on this node)" if use_p2p else
@@ -304,6 +305,11 @@ def run_sharded(args) -> dict:
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     errs = drv.mean_errors()
+    # the timed run started from the same factors as the collective reference of the set-up: its first sweeps must be the same bits
+    verified = None
+    if use_p2p and tab_ref is not None:
+        tab_run = drv.view_error_table()
+        verified = bool(len(tab_run) >= len(tab_ref) and np.array_equal(tab_run[:len(tab_ref)], tab_ref))
     replicated = any(drv.replicated)
     allgather = drv.allgather_layout
     replicated_gs = drv.replicate_gs
@@ -401,7 +407,7 @@ def run_sharded(args) -> dict:
                                + " (all rows / columns of coupled views shared), one view per GPU, Gauss-Seidel order kept exactly; " + layout,
                    "n_views": n_views, "shapes": [list(sh) for sh in shapes], "k": k,
                    "backend": ("rccl" if backend == "nccl" else backend), "world_size": world, "distinct_devices": n_devices,
-                   "exchange": p2p_note, "sweeps_per_graph_replay": (chunk if captured else 0),
+                   "exchange": p2p_note, "timed_run_first_sweeps_equal_collective_reference": verified, "sweeps_per_graph_replay": (chunk if captured else 0),
                    "final_error": float(errs[-1]) if len(errs) else None,
                    "scaling_note": "BASELINE.json prescribes a different workload per GPU count (c3 / c4 / c5): compare value / n_gpus "
                                    "with the one-view rate of the same shape (roofline.single_view_updates_per_s), not across N"},
