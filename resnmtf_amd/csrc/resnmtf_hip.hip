@@ -28,6 +28,12 @@
 
 #include "resnmtf_hip.h"
 #include "resnmtf_kernels.hip.inc"
+#ifdef RESNMTF_SPLIT_TU      // product build: the k <= 16 pass lives in resnmtf_pass_k16.hip (its own scheduling strategy)
+#include "resnmtf_split_tu.h"
+#define RESNMTF_EXTERN(NW, UNR, XG, MA) extern template __global__ void pass_kernel<1, NW, UNR, XG, MA, 0>(PassArgs, KKFArgs, KKSArgs);
+RESNMTF_PASS_K16_LIST(RESNMTF_EXTERN)
+#undef RESNMTF_EXTERN
+#endif
 
 namespace {
 
