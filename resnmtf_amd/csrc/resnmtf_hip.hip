@@ -28,8 +28,8 @@
 
 #include "resnmtf_hip.h"
 #include "resnmtf_kernels.hip.inc"
-#ifdef RESNMTF_SPLIT_TU      // product build: the k <= 16 pass lives in resnmtf_pass_k16.hip (its own scheduling strategy)
 #include "resnmtf_split_tu.h"
+#ifdef RESNMTF_SPLIT_TU      // product build: the k <= 16 pass lives in resnmtf_pass_k16.hip (its own scheduling strategy)
 #define RESNMTF_EXTERN(NW, UNR, XG, MA) extern template __global__ void pass_kernel<1, NW, UNR, XG, MA, 0>(PassArgs, KKFArgs, KKSArgs);
 RESNMTF_PASS_K16_LIST(RESNMTF_EXTERN)
 #undef RESNMTF_EXTERN
@@ -464,7 +464,7 @@ void launch_pass(resnmtf_handle* h, const ViewState& v, bool xg, int mode, doubl
   else { LAUNCH_PASS_M(NTV, NWV, UV, false, false); }
   switch (v.NT * 100 + nw) {
     case 104: LAUNCH_PASS(1, 4, 8); break;
-    case 108: if (xg ? v.pp_xg : v.pp_xtf) { LAUNCH_PASS(1, 8, 4); } else { LAUNCH_PASS(1, 8, 8); } break;
+    case 108: if (xg ? v.pp_xg : v.pp_xtf) { LAUNCH_PASS(1, 8, 4); } else { LAUNCH_PASS(1, 8, RESNMTF_K16_UNROLL); } break;
     case 116: LAUNCH_PASS(1, 16, 8); break;
     case 208: LAUNCH_PASS(2, 8, 4); break;
     case 308: LAUNCH_PASS(3, 8, 4); break;
