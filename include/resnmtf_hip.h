@@ -118,8 +118,8 @@ typedef struct resnmtf_options {
   int time_kernels;       /* 1: bracket every streaming-pass launch with HIP events (eager mode) */
   /* tuning overrides of the streaming-pass geometry (0 = automatic), see DESIGN.md section 5 */
   int pass_waves;         /* waves per workgroup: 4, 8 or 16 (0 = auto) */
-  int pass_splits_xg;     /* row splits of the X.G pass */
-  int pass_splits_xtf;    /* row splits of the Xt.F pass */
+  int pass_splits_xg;     /* row splits of the X.G pass: 0 (default) = the launch model's choice, else 1 ... 16 (refused beyond) */
+  int pass_splits_xtf;    /* row splits of the Xt.F pass: likewise */
   int pass_lds_pad_kb;    /* extra dynamic LDS per workgroup (caps workgroups per CU) */
   int update_blocks;      /* workgroups per factor-update launch; 0 = default: ~160 (512 above 256 MB of X) in hand-off
                              mode A, one round of resident workgroups (CUs x 1 at k > 32, x 2 at k = 32) in mode B */

@@ -1141,6 +1141,10 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     if (opts->struct_size != (int)sizeof(resnmtf_options)) { g_create_error = "options struct_size mismatch"; return RESNMTF_ERR_INVALID; }
     o = *opts;
   }
+  if (o.pass_splits_xg < 0 || o.pass_splits_xg > 16 || o.pass_splits_xtf < 0 || o.pass_splits_xtf > 16) {
+    g_create_error = "pass_splits_xg / pass_splits_xtf must be in 0 ... 16 (0 = the launch model's choice)";      // (a forced count beyond
+    return RESNMTF_ERR_INVALID;                                                                          //  the planner's range found no plan)
+  }
   if (o.bf16_split == 1) { g_create_error = "bf16_split = 1 (the two-piece form) is retired: use 0 (three pieces, f32-grade) or 2 (f32 MFMA)"; return RESNMTF_ERR_INVALID; }
   if (o.slice_chains) {
     const char* why = nullptr;

@@ -81,6 +81,15 @@ def test_torch_imported_after_the_library_still_finds_the_gpu():
     assert out.returncode == 0 and "torch after library: ok True" in out.stdout, out.stdout + out.stderr
 
 
+def test_forced_row_splits_are_range_checked():
+    """pass_splits_xg / pass_splits_xtf (tuning options): a count the launch planner cannot place is refused at create."""
+    with pytest.raises(ResnmtfError, match="pass_splits"):
+        Engine([300], [200], [24], pass_splits_xtf=20)
+    with pytest.raises(ResnmtfError, match="pass_splits"):
+        Engine([300], [200], [5], pass_splits_xg=-1)
+    Engine([300], [200], [24], pass_splits_xtf=16).close()
+
+
 def test_sliced_layout_options_are_checked():
     """slice_chains / slice_p2p (round 3): layouts that cannot be sliced are refused at create with a message, the peer-store
     exchange insists on its set-up order, the stop tolerance of the phase API on a replicated S chain."""
