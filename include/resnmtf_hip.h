@@ -113,7 +113,7 @@ typedef struct resnmtf_options {
                              length for short fixed runs, else batches of check_every and a power-of-two ladder for the rest) */
   int check_every;        /* convergence mode: sweeps enqueued per host-side check (default 32; launches after the stop
                              test fired return at once) */
-  int target_workgroups;  /* workgroup slots a streaming pass is sized for; 0 = default: CUs x resident workgroups per CU
+  int target_workgroups;  /* workgroup slots a streaming pass is sized for (>= 64, smaller values are refused); 0 = default: CUs x resident workgroups per CU
                              (two at k <= 16, one above) */
   int time_kernels;       /* 1: bracket every streaming-pass launch with HIP events (eager mode) */
   /* tuning overrides of the streaming-pass geometry (0 = automatic), see DESIGN.md section 5 */

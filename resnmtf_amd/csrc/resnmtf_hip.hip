@@ -1145,6 +1145,10 @@ int resnmtf_create(int n_views, const int* n_rows, const int* n_cols, const int*
     g_create_error = "pass_splits_xg / pass_splits_xtf must be in 0 ... 16 (0 = the launch model's choice)";      // (a forced count beyond
     return RESNMTF_ERR_INVALID;                                                                          //  the planner's range found no plan)
   }
+  if (o.target_workgroups != 0 && o.target_workgroups < 64) {      // (the launch planner needs room for the aux workgroups of the k > 16 passes)
+    g_create_error = "target_workgroups must be 0 (the device's own figure) or at least 64";
+    return RESNMTF_ERR_INVALID;
+  }
   if (o.bf16_split == 1) { g_create_error = "bf16_split = 1 (the two-piece form) is retired: use 0 (three pieces, f32-grade) or 2 (f32 MFMA)"; return RESNMTF_ERR_INVALID; }
   if (o.slice_chains) {
     const char* why = nullptr;

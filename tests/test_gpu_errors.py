@@ -142,3 +142,38 @@ def test_sliced_layout_options_are_checked():
     with pytest.raises(ResnmtfError, match="not a slice_chains handle"):
         one.slice_info()
     one.close()
+
+
+@pytest.mark.parametrize("k", [5, 24, 64])
+def test_tuning_options_outside_their_range_never_change_the_answer(k):
+    """The tuning fields of resnmtf_options (waves, splits, blocks, pads, modes) with values outside what the library
+    documents: a handle is either refused at create or computes what the default handle computes -- against the oracle, so
+    that an option which silently mis-sizes a launch (as a forced split count beyond the planner's range once did) shows."""
+    from helpers import rel_fro, run_oracle
+    n, m = (700, 260) if k == 64 else (300, 200)
+    prob = synth.make_problem([(n, m)], k)
+    ref = run_oracle(prob, n_iters=6)
+    weird = [dict(pass_waves=3), dict(pass_waves=5), dict(pass_waves=16), dict(update_blocks=1), dict(update_blocks=100000),
+             dict(target_workgroups=1), dict(target_workgroups=64), dict(target_workgroups=97), dict(target_workgroups=1000000), dict(pass_lds_pad_kb=-3), dict(pass_lds_pad_kb=4096),
+             dict(check_every=0), dict(check_every=-5), dict(half_unroll=7), dict(x_half=9), dict(kk_mode=7), dict(kk_mode=-1),
+             dict(wait_mode=11), dict(pass_splits_xg=16), dict(pass_splits_xtf=16), dict(pass_splits_xg=1, pass_splits_xtf=1),
+             dict(no_pitch_pad=True, pass_waves=4), dict(xcd_order=True), dict(bf16_split=2), dict(bf16_split=5)]
+    refused, wrong = 0, []
+    for opts in weird:
+        try:
+            e = Engine([n], [m], [k], **opts)
+        except ResnmtfError:
+            refused += 1
+            continue
+        try:
+            e.set_view(0, prob.data[0]); e.set_restrictions()
+            e.set_factors(0, prob.init_f[0], prob.init_s[0], prob.init_g[0])
+            errs = e.run(6)
+            f, s, g, _, _ = e.finalise(0)
+        finally:
+            e.close()
+        if not (np.allclose(errs, ref["All_Error"], atol=2e-5, rtol=1e-4) and rel_fro(f, ref["output_f"][0]) < 1e-4
+                and rel_fro(g, ref["output_g"][0]) < 1e-4):
+            wrong.append(opts)
+    assert not wrong, wrong
+    assert refused <= 8        # (most out-of-range values fall back to the default; a few are refused with a message)
