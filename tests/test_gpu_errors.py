@@ -157,7 +157,10 @@ def test_tuning_options_outside_their_range_never_change_the_answer(k):
              dict(target_workgroups=1), dict(target_workgroups=64), dict(target_workgroups=97), dict(target_workgroups=1000000), dict(pass_lds_pad_kb=-3), dict(pass_lds_pad_kb=4096),
              dict(check_every=0), dict(check_every=-5), dict(half_unroll=7), dict(x_half=9), dict(kk_mode=7), dict(kk_mode=-1),
              dict(wait_mode=11), dict(pass_splits_xg=16), dict(pass_splits_xtf=16), dict(pass_splits_xg=1, pass_splits_xtf=1),
-             dict(no_pitch_pad=True, pass_waves=4), dict(xcd_order=True), dict(bf16_split=2), dict(bf16_split=5)]
+             dict(no_pitch_pad=True, pass_waves=4), dict(xcd_order=True), dict(bf16_split=2), dict(bf16_split=5),
+             dict(use_graph=False), dict(time_kernels=True), dict(replicate_f=True), dict(replicate_f=True, replicate_gs=True),
+             dict(no_f_chain=True), dict(fuse_updates=1), dict(fuse_updates=2), dict(fuse_updates=9), dict(slice_index=3, slice_count=5),
+             dict(use_graph=False, check_every=1), dict(target_workgroups=200, pass_splits_xtf=3)]
     refused, wrong = 0, []
     for opts in weird:
         try:
@@ -170,10 +173,13 @@ def test_tuning_options_outside_their_range_never_change_the_answer(k):
             e.set_factors(0, prob.init_f[0], prob.init_s[0], prob.init_g[0])
             errs = e.run(6)
             f, s, g, _, _ = e.finalise(0)
+        except ResnmtfError:               # (e.g. replicate_gs: resnmtf_run says it is the phase API's layout)
+            refused += 1
+            continue
         finally:
             e.close()
         if not (np.allclose(errs, ref["All_Error"], atol=2e-5, rtol=1e-4) and rel_fro(f, ref["output_f"][0]) < 1e-4
                 and rel_fro(g, ref["output_g"][0]) < 1e-4):
             wrong.append(opts)
     assert not wrong, wrong
-    assert refused <= 8        # (most out-of-range values fall back to the default; a few are refused with a message)
+    assert refused <= 10        # (most out-of-range values fall back to the default; a few are refused with a message)
