@@ -183,3 +183,48 @@ def test_tuning_options_outside_their_range_never_change_the_answer(k):
             wrong.append(opts)
     assert not wrong, wrong
     assert refused <= 10        # (most out-of-range values fall back to the default; a few are refused with a message)
+
+
+@pytest.mark.parametrize("k", [7, 40])
+def test_tuning_options_on_coupled_views_never_change_the_answer(k):
+    """The same question for three views coupled through phi, psi and xi with names shared in part (the coupled update
+    kernels, the k x k chains with their S couplings, the fused chains): every accepted option set computes the oracle's answer."""
+    from helpers import coupled_problem, rel_fro, run_oracle
+    shapes = [(210, 150), (190, 150), (210, 120)]
+    prob = coupled_problem(shapes, k, seed=91, phi_w=1.5, psi_w=1.0, xi_w=0.4)
+    ref = run_oracle(prob, n_iters=5)
+    from resnmtf_amd import naming
+    row_sh, col_sh = naming.shared_names(prob.row_names), naming.shared_names(prob.col_names)
+    sets = [dict(), dict(update_blocks=1), dict(update_blocks=977), dict(pass_waves=16), dict(target_workgroups=64), dict(no_f_chain=True),
+            dict(use_graph=False), dict(kk_mode=1), dict(kk_mode=2), dict(pass_splits_xg=2, pass_splits_xtf=9), dict(time_kernels=True, use_graph=False),
+            dict(check_every=1), dict(wait_mode=1), dict(bf16_split=2), dict(xcd_order=True), dict(fuse_updates=1)]
+    wrong, accepted = [], 0
+    for opts in sets:
+        try:
+            e = Engine([s[0] for s in shapes], [s[1] for s in shapes], [k] * 3, **opts)
+        except ResnmtfError:
+            continue
+        try:
+            for v in range(3):
+                e.set_view(v, prob.data[v])
+                e.set_factors(v, prob.init_f[v], prob.init_s[v], prob.init_g[v])
+            e.set_restrictions(prob.phi, prob.xi, prob.psi)
+            for v in range(3):
+                for w in range(3):
+                    if w != v:
+                        e.set_shared_rows(v, w, *naming.index_pairs(prob.row_names[v], prob.row_names[w], row_sh[v].get(w)))
+                        e.set_shared_cols(v, w, *naming.index_pairs(prob.col_names[v], prob.col_names[w], col_sh[v].get(w)))
+            errs = e.run(5)
+            outs = [e.finalise(v) for v in range(3)]
+        except ResnmtfError:
+            continue
+        finally:
+            e.close()
+        ok = np.allclose(errs, ref["All_Error"], atol=2e-5, rtol=1e-4)
+        for v in range(3):
+            ok = ok and rel_fro(outs[v][0], ref["output_f"][v]) < 1e-4 and rel_fro(outs[v][2], ref["output_g"][v]) < 1e-4
+        accepted += 1
+        if not ok:
+            wrong.append(opts)
+    assert not wrong, wrong
+    assert accepted >= 12, accepted      # (the test is about the sets that run)
